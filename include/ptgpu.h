@@ -1,0 +1,164 @@
+/*
+ * ptgpu -- MI355X (gfx950) implementation of PathTracer's per-pixel Monte Carlo integrator and
+ * ray-scene intersection, behind a C ABI.
+ *
+ * The reference program has no plugin/FFI interface for this path; the boundary is the set of D call
+ * sites that the host program keeps (all citations are into the reference checkout):
+ *
+ *   scene ready      end of loadScene()                       rendering.d:70-162
+ *   render call      computeOutputColor(offset, pixels, gen)   rendering.d:494-500, main.d:120-123
+ *   frame read-back  drawScreen(screen, pixels)                main.d:31-99, main.d:275
+ *   checkpoint       RawFile("sponza.project") of Pixel[]      main.d:227-234, 333-340
+ *
+ * Conventions: every function returns 0 on success or a negative PT_E_* code; ptgpu_last_error()
+ * returns a message for the calling thread.  No exception crosses this boundary (the reference throws
+ * RCException, modelloader.d:134, scene.d:1007).  All structs are plain data, fp32/uint32 only.
+ * Functions on ONE handle are not re-entrant; different handles (= different GPUs) may be driven from
+ * different threads.  Host memory passed in is copied before return and never freed by the library.
+ */
+#ifndef PTGPU_H
+#define PTGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_OK 0
+#define PT_E_INVALID (-1)   /* bad argument / out-of-range pixel window            */
+#define PT_E_STATE (-2)     /* call order: scene or camera not set                  */
+#define PT_E_DEVICE (-3)    /* HIP runtime error (message has the hipError string)  */
+#define PT_E_IO (-4)        /* file missing / not a thModel / malformed chunk       */
+#define PT_E_NOMEM (-5)
+
+typedef struct PtHandle PtHandle;
+
+/* The reference's source-level switches as one POD (rendering.d:19-21 resolution, :54-55 g_hasSky /
+ * g_hasLights, :72-74 sun + sky, :379-380 Russian roulette 0.7 / depth 5, :466 N = 5, FloatEpsilon). */
+typedef struct PtConfig {
+  int32_t device;            /* HIP device ordinal                                                    */
+  uint32_t width, height;    /* g_width, g_height                                                     */
+  uint32_t mode;             /* 0 = HEAD behaviour: direct lighting only (rendering.d:477)            */
+                             /* 1 = + numIndirect computeLindirect chains (the block at :474-477)     */
+  uint32_t hasSky;           /* g_hasSky                                                              */
+  uint32_t hasLights;        /* g_hasLights                                                           */
+  float sunDir[3];           /* g_sunDir      (normalised by the caller)                              */
+  float sunRadiance[3];      /* g_sunRadiance                                                         */
+  float skyRadiance[3];      /* g_skyRadiance                                                         */
+  float floatEpsilon;        /* thBase FloatEpsilon (not in the reference checkout); 1e-5 if 0        */
+  float rrProb;              /* `absorb` of computeLindirect, 0.7 if 0                                */
+  uint32_t maxDepth;         /* depth cap of computeLindirect, 5 if 0                                 */
+  uint32_t numIndirect;      /* N of computeL, 5 if 0                                                 */
+  uint32_t seed;             /* RNG key; streams are keyed (seed, pixel, sample, stream)              */
+  uint32_t sampleBase;       /* added to a pixel's sample index: sample-slice split across GPUs       */
+  uint32_t batchSlots;       /* path slots per wavefront batch, 0 = default                           */
+  uint32_t maxLeafTris;      /* BVH leaf size bound (1..15), 0 = default                              */
+  uint32_t flags;            /* PT_FLAG_*                                                             */
+} PtConfig;
+
+#define PT_FLAG_COUNT_VISITS 1u   /* count BVH node boxes tested / triangles tested per ray kind (slow) */
+#define PT_FLAG_NO_LDS_SCENE 2u   /* keep nodes/triangles in global memory even if they fit in LDS     */
+#define PT_FLAG_TIME_KERNELS 4u   /* bracket every kernel launch with events (ptgpu_get_stats)         */
+
+typedef struct PtMaterial { float emissive; float color[3]; } PtMaterial;        /* rendering.d:33-37 */
+typedef struct PtPixel { float color[3]; float n; float sum[3]; } PtPixel;        /* rendering.d:24-30 */
+
+/* Kernel kinds reported by ptgpu_get_stats */
+enum { PT_K_EXTEND = 0, PT_K_CONNECT = 1, PT_K_OCCLUDED = 2, PT_K_SHADE = 3, PT_K_ACCUM = 4, PT_K_OTHER = 5, PT_K_COUNT = 6 };
+
+typedef struct PtStats {
+  uint64_t raysPrimary;      /* Scene.trace calls from computeL             (rendering.d:471)            */
+  uint64_t raysLight;        /* Scene.trace calls from computeLdirect        (rendering.d:414)            */
+  uint64_t raysIndirect;     /* Scene.trace calls from computeLindirect      (rendering.d:389)            */
+  uint64_t raysOcclusion;    /* Scene.hitsNothing calls                      (rendering.d:440,455)        */
+  uint64_t samples;          /* computeL invocations                                                     */
+  uint64_t nodesClosest, trisClosest;   /* with PT_FLAG_COUNT_VISITS: box tests / triangle tests, closest-hit rays */
+  uint64_t nodesAny, trisAny;           /* same for any-hit rays                                          */
+  double kernelMs[PT_K_COUNT];          /* with PT_FLAG_TIME_KERNELS: summed event time per kernel kind   */
+  uint64_t kernelLaunches[PT_K_COUNT];
+  double renderMs;           /* event time first kernel -> last kernel of all ptgpu_render calls          */
+  uint32_t numTriangles, numNodes, bvhDepth, numLightGroups;
+  uint32_t sceneInLds;       /* 1 if nodes + triangles are staged in LDS by the traversal kernels         */
+  uint32_t reserved;
+} PtStats;
+
+const char* ptgpu_last_error(void);
+
+/* New!Camera + New!Scene happen on a handle.  Replaces the globals g_camera/g_scene (rendering.d:17-18). */
+int ptgpu_create(const PtConfig* cfg, PtHandle** out);
+int ptgpu_destroy(PtHandle* h);
+/* Switch any PtConfig field except device/width/height/batchSlots after creation. */
+int ptgpu_set_config(PtHandle* h, const PtConfig* cfg);
+
+/* Scene from flattened triangles: what Scene's accessors expose after construction (scene.d:925-946):
+ * v = T x (v0,v1,v2) world-space positions, n = T x 3 vertex normals, matIdx = T material indices,
+ * mats = M materials.  Builds the acceleration structure, the light groups (one per emissive material,
+ * rendering.d:116-161) and uploads everything. */
+int ptgpu_upload_scene(PtHandle* h, const float* v, const float* n, const uint32_t* matIdx, const PtMaterial* mats,
+                       uint32_t numTriangles, uint32_t numMaterials);
+
+/* New!Scene(path, matFunc, modelMatrix) for a .thModel file (scene.d:193-321, modelloader.d:125-704).
+ * materialTable: 0 = fillMaterial (rendering.d:247-275), 1 = fillMaterialCitymap (rendering.d:195-244).
+ * modelMatrix: 16 floats, row-major, row-vector convention; NULL = inverse(root node transform), which
+ * puts the scene in raw mesh space. */
+int ptgpu_load_thmodel(PtHandle* h, const char* path, int materialTable, const float* modelMatrix);
+
+/* Read the flattened scene back (host copies): pass NULL to skip an array.  Sizes from ptgpu_get_stats. */
+int ptgpu_get_scene(PtHandle* h, float* v, float* n, uint32_t* matIdx, PtMaterial* mats, uint32_t* numMaterials);
+/* Light table as built by loadScene: for group g, up to cap rows of 11 floats (v0,e1,e2,area,probability). */
+int ptgpu_get_light_group(PtHandle* h, uint32_t g, float* rows11, uint32_t cap, uint32_t* count, float* totalArea);
+/* Flattened BVH: nodes = numNodes x 8 floats (min.xyz, ref, max.xyz, unused), refs as uint32 bit patterns;
+ * triOrder = numTriangles original triangle ids in leaf order. */
+int ptgpu_get_bvh(PtHandle* h, float* nodes8, uint32_t* triOrder);
+
+/* Exactly Camera's private state (camera.d:11-12) ... */
+int ptgpu_set_camera(PtHandle* h, const float pos[3], const float dir[3], const float right[3], const float up[3],
+                     float tanFov, float aspect);
+/* ... or Camera(fov, aspect) + setTransform(from, to, up) (camera.d:16-29). out14 (optional) receives
+ * pos dir right up tanFov aspect. */
+int ptgpu_camera_look_at(PtHandle* h, float fovDegrees, float aspect, const float from[3], const float to[3],
+                         const float up[3], float* out14);
+
+/* computeOutputColor(pixelOffset, pixels[0..pixelCount], gen) repeated spp times (rendering.d:494-500):
+ * every pixel of the window gets spp more samples; sum += L, n += 1, color = sum / n.  Asynchronous on
+ * the handle's stream. */
+int ptgpu_render(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount, uint32_t spp);
+/* The reference's task decomposition (main.d:184-192) as one call: renders the scanline bands
+ * b = bandFirst, bandFirst + bandStride, ... (band = bandRows rows) -- the per-GPU share of a frame. */
+int ptgpu_render_bands(PtHandle* h, uint32_t bandRows, uint32_t bandFirst, uint32_t bandStride, uint32_t spp);
+int ptgpu_synchronize(PtHandle* h);
+
+/* Pixel[] access for drawScreen (main.d:275) and the project file (main.d:227-234, 333-340). */
+int ptgpu_read_pixels(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount, PtPixel* out);
+int ptgpu_write_pixels(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount, const PtPixel* in);
+int ptgpu_clear_pixels(PtHandle* h);
+/* drawScreen's scalar path on the device: saturate -> sRGB OETF -> (ubyte)(x*255), 3 bytes per pixel (main.d:82-95). */
+int ptgpu_tonemap(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount, uint8_t* rgb);
+
+/* Scene.trace (scene.d:681-743) for caller-supplied rays, 6 floats each (pos, dir): closest front-face hit.
+ * Outputs may be NULL.  triId = -1 and t = FLT_MAX on a miss. */
+int ptgpu_scene_trace(PtHandle* h, const float* rays6, uint32_t count, int32_t* triId, float* t, float* u, float* v,
+                      float* normal3);
+/* Scene.hitsNothing (scene.d:801-838): out[i] = 1 if ray i hits no geometry. */
+int ptgpu_scene_hits_nothing(PtHandle* h, const float* rays6, uint32_t count, uint8_t* out);
+/* Parity probe: getViewRay without jitter (rendering.d:278-285) + Scene.trace for a pixel window. */
+int ptgpu_trace_primary(PtHandle* h, uint32_t pixelOffset, uint32_t count, int32_t* triId, float* t, float* u, float* v);
+/* The view rays themselves, 6 floats each. */
+int ptgpu_view_rays(PtHandle* h, uint32_t pixelOffset, uint32_t count, float* rays6);
+/* First n words of RNG stream (seed, pixel, sample, stream) as the kernels draw them. */
+int ptgpu_rng_stream(PtHandle* h, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n, uint32_t* out);
+
+int ptgpu_get_stats(PtHandle* h, PtStats* out);
+int ptgpu_reset_stats(PtHandle* h);
+
+/* Plumbing for callers that own device memory and streams (one process per GPU with torch.distributed):
+ * the accumulator is width*height float4 (sum.r, sum.g, sum.b, n) in device memory. */
+int ptgpu_bind_accumulator(PtHandle* h, void* devicePtr, uint64_t bytes);
+int ptgpu_get_accumulator(PtHandle* h, void** devicePtr, uint64_t* bytes);
+int ptgpu_set_stream(PtHandle* h, void* hipStream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,264 @@
+"""Host-side mirror of the reference's interface for its integrator + intersection path, on top of the
+C ABI in include/ptgpu.h.  Names follow the reference where it has one:
+
+  Camera(fov, aspectRatio), Camera.setTransform(from, to, up)        camera.d:16-29
+  Scene(path, matFunc, modelMatrix), Scene.trace, Scene.hitsNothing  scene.d:193, 681, 801
+  computeOutputColor(pixelOffset, pixels, gen)                        rendering.d:494-500
+  Pixel {color, n, sum}                                               rendering.d:24-30
+  drawScreen's tone map                                               main.d:82-95
+
+The renderer is the GPU library; nothing here computes radiance or intersections on the CPU.
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._lib import PtConfig, PtStats
+
+PIXEL_DTYPE = np.dtype([('color', '<f4', 3), ('n', '<f4'), ('sum', '<f4', 3)])      # rendering.d:24-30
+MATERIAL_DTYPE = np.dtype([('emissive', '<f4'), ('color', '<f4', 3)])                # rendering.d:33-37
+
+# material tables selectable in Scene(): rendering.d:247-275 and rendering.d:195-244
+FILL_MATERIAL, FILL_MATERIAL_CITYMAP = 0, 1
+
+
+class PtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('ptgpu error %d: %s' % (code, msg))
+        self.code = code
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def default_sun_dir():
+    """g_sunDir = vec3(1,1,3).normalized()  (rendering.d:72)"""
+    v = np.array([1, 1, 3], np.float32)
+    return (v * (np.float32(1.0) / np.sqrt(np.float32(11.0), dtype=np.float32))).astype(np.float32)
+
+
+def default_sky_radiance():
+    """g_skyRadiance = vec3(0.682, 0.977, 1.0) * 0.1  (rendering.d:74)"""
+    return (np.array([0.682, 0.977, 1.0], np.float32) * np.float32(0.1)).astype(np.float32)
+
+
+class Camera:
+    """camera.d: the 14 floats of state are computed by the library (ptgpu_camera_look_at)."""
+
+    def __init__(self, fov, aspectRatio):
+        self.fov, self.aspect = float(fov), float(aspectRatio)
+        self.state = None
+
+    def setTransform(self, frm, to, up):
+        out = np.zeros(14, np.float32)
+        f, t, u = (np.ascontiguousarray(x, np.float32) for x in (frm, to, up))
+        rc = _lib.load().ptgpu_camera_look_at(None, self.fov, self.aspect, _ptr(f), _ptr(t), _ptr(u), _ptr(out))
+        if rc:
+            raise PtError(rc, _lib.load().ptgpu_last_error().decode())
+        self.state = out
+        return self
+
+
+class PathTracer:
+    """One GPU's renderer: owns what the reference keeps in g_camera / g_scene / Pixel[]."""
+
+    def __init__(self, width, height, device=0, **kw):
+        self.lib = _lib.load()
+        self.cfg = PtConfig()
+        self.cfg.device, self.cfg.width, self.cfg.height = device, width, height
+        self.cfg.hasLights = 1                                        # rendering.d:55
+        self.cfg.sunDir[:] = [float(x) for x in default_sun_dir()]     # rendering.d:72-74
+        self.cfg.sunRadiance[:] = [1.0, 0.984, 0.8]
+        self.cfg.skyRadiance[:] = [float(x) for x in default_sky_radiance()]
+        self._apply(kw)
+        h = C.c_void_p()
+        self._check(self.lib.ptgpu_create(C.byref(self.cfg), C.byref(h)))
+        self.h = h
+        self.width, self.height = width, height
+        self._acc_keepalive = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc != 0:
+            raise PtError(rc, self.lib.ptgpu_last_error().decode(errors='replace'))
+
+    _ALIASES = {'has_sky': 'hasSky', 'has_lights': 'hasLights', 'eps': 'floatEpsilon', 'rr': 'rrProb',
+                'max_depth': 'maxDepth', 'n_indirect': 'numIndirect', 'sample_base': 'sampleBase',
+                'batch_slots': 'batchSlots', 'max_leaf_tris': 'maxLeafTris', 'sun_dir': 'sunDir',
+                'sun_radiance': 'sunRadiance', 'sky_radiance': 'skyRadiance'}
+
+    def _apply(self, kw):
+        for k, v in kw.items():
+            k = self._ALIASES.get(k, k)
+            if not hasattr(self.cfg, k):
+                raise TypeError('unknown config field %r' % k)
+            if k in ('sunDir', 'sunRadiance', 'skyRadiance'):
+                getattr(self.cfg, k)[:] = [float(x) for x in v]
+            elif k in ('floatEpsilon', 'rrProb'):
+                setattr(self.cfg, k, float(v))
+            else:
+                setattr(self.cfg, k, int(v))
+
+    def set_config(self, **kw):
+        self._apply(kw)
+        self._check(self.lib.ptgpu_set_config(self.h, C.byref(self.cfg)))
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.ptgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ scene + camera
+    def Scene(self, path, matFunc=FILL_MATERIAL, modelMatrix=None):
+        """New!Scene(path, matFunc, modelMatrix) (scene.d:193); modelMatrix None = raw mesh space."""
+        mm = None if modelMatrix is None else np.ascontiguousarray(modelMatrix, np.float32).reshape(16)
+        self._check(self.lib.ptgpu_load_thmodel(self.h, str(path).encode(), int(matFunc), _ptr(mm)))
+        return self
+
+    def upload_scene(self, v, n, mat_idx, materials):
+        v = np.ascontiguousarray(v, np.float32).reshape(-1, 9)
+        n = np.ascontiguousarray(n, np.float32).reshape(-1, 9)
+        mi = np.ascontiguousarray(mat_idx, np.uint32)
+        m = np.ascontiguousarray(materials, np.float32).reshape(-1, 4)
+        if not (len(v) == len(n) == len(mi)):
+            raise ValueError('v, n and mat_idx must describe the same number of triangles')
+        self._check(self.lib.ptgpu_upload_scene(self.h, _ptr(v), _ptr(n), _ptr(mi), _ptr(m), len(v), len(m)))
+        return self
+
+    def get_scene(self):
+        st = self.stats()
+        T = st.numTriangles
+        v = np.zeros((T, 9), np.float32); n = np.zeros((T, 9), np.float32); mi = np.zeros(T, np.uint32)
+        mats = np.zeros((256, 4), np.float32); nm = C.c_uint32()
+        self._check(self.lib.ptgpu_get_scene(self.h, _ptr(v), _ptr(n), _ptr(mi), None, C.byref(nm)))
+        mats = np.zeros((nm.value, 4), np.float32)
+        self._check(self.lib.ptgpu_get_scene(self.h, None, None, None, _ptr(mats), None))
+        return {'v': v.reshape(T, 3, 3), 'n': n.reshape(T, 3, 3), 'mat_idx': mi, 'materials': mats}
+
+    def light_groups(self):
+        """g_lightTriangles / g_totalLightSourceArea (rendering.d:47-48)."""
+        out = []
+        T = max(1, self.stats().numTriangles)
+        for g in range(self.stats().numLightGroups):
+            rows = np.zeros((T, 11), np.float32); cnt = C.c_uint32(); area = C.c_float()
+            self._check(self.lib.ptgpu_get_light_group(self.h, g, _ptr(rows), T, C.byref(cnt), C.byref(area)))
+            out.append((rows[:cnt.value].copy(), area.value))
+        return out
+
+    def get_bvh(self):
+        st = self.stats()
+        nodes = np.zeros((st.numNodes, 8), np.float32)
+        order = np.zeros(max(1, st.numTriangles), np.uint32)
+        self._check(self.lib.ptgpu_get_bvh(self.h, _ptr(nodes), _ptr(order)))
+        return nodes, order
+
+    def set_camera(self, cam):
+        """cam: Camera (after setTransform) or 14 floats pos dir right up tanFov aspect (camera.d:11-12)."""
+        s = np.ascontiguousarray(cam.state if isinstance(cam, Camera) else cam, np.float32)
+        self._check(self.lib.ptgpu_set_camera(self.h, _ptr(s[0:3].copy()), _ptr(s[3:6].copy()), _ptr(s[6:9].copy()),
+                                              _ptr(s[9:12].copy()), float(s[12]), float(s[13])))
+        return self
+
+    # ------------------------------------------------------------------ rendering
+    def computeOutputColor(self, pixelOffset, pixelCount, spp=1):
+        """rendering.d:494-500 for a whole window of pixels, spp passes (asynchronous)."""
+        self._check(self.lib.ptgpu_render(self.h, pixelOffset, pixelCount, spp))
+
+    render = computeOutputColor
+
+    def render_frame(self, spp):
+        self.computeOutputColor(0, self.width * self.height, spp)
+
+    def render_bands(self, band_rows, band_first, band_stride, spp):
+        """main.d:184-192's 4-scanline tasks, every band_stride-th band starting at band_first."""
+        self._check(self.lib.ptgpu_render_bands(self.h, band_rows, band_first, band_stride, spp))
+
+    def synchronize(self):
+        self._check(self.lib.ptgpu_synchronize(self.h))
+
+    def read_pixels(self, offset=0, count=None):
+        count = self.width * self.height - offset if count is None else count
+        out = np.zeros(count, PIXEL_DTYPE)
+        self._check(self.lib.ptgpu_read_pixels(self.h, offset, count, _ptr(out)))
+        return out
+
+    def write_pixels(self, pixels, offset=0):
+        pixels = np.ascontiguousarray(pixels, PIXEL_DTYPE)
+        self._check(self.lib.ptgpu_write_pixels(self.h, offset, len(pixels), _ptr(pixels)))
+
+    def clear_pixels(self):
+        self._check(self.lib.ptgpu_clear_pixels(self.h))
+
+    def tonemap(self, offset=0, count=None):
+        count = self.width * self.height - offset if count is None else count
+        out = np.zeros((count, 3), np.uint8)
+        self._check(self.lib.ptgpu_tonemap(self.h, offset, count, _ptr(out)))
+        return out
+
+    # ------------------------------------------------------------------ Scene.trace / Scene.hitsNothing
+    def trace(self, rays6):
+        rays6 = np.ascontiguousarray(rays6, np.float32).reshape(-1, 6); n = len(rays6)
+        tri = np.zeros(n, np.int32); t = np.zeros(n, np.float32); u = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+        nrm = np.zeros((n, 3), np.float32)
+        self._check(self.lib.ptgpu_scene_trace(self.h, _ptr(rays6), n, _ptr(tri), _ptr(t), _ptr(u), _ptr(v), _ptr(nrm)))
+        return tri, t, u, v, nrm
+
+    def hitsNothing(self, rays6):
+        rays6 = np.ascontiguousarray(rays6, np.float32).reshape(-1, 6); n = len(rays6)
+        out = np.zeros(n, np.uint8)
+        self._check(self.lib.ptgpu_scene_hits_nothing(self.h, _ptr(rays6), n, _ptr(out)))
+        return out.astype(bool)
+
+    def trace_primary(self, offset=0, count=None):
+        count = self.width * self.height - offset if count is None else count
+        tri = np.zeros(count, np.int32); t = np.zeros(count, np.float32)
+        u = np.zeros(count, np.float32); v = np.zeros(count, np.float32)
+        self._check(self.lib.ptgpu_trace_primary(self.h, offset, count, _ptr(tri), _ptr(t), _ptr(u), _ptr(v)))
+        return tri, t, u, v
+
+    def view_rays(self, offset=0, count=None):
+        count = self.width * self.height - offset if count is None else count
+        out = np.zeros((count, 6), np.float32)
+        self._check(self.lib.ptgpu_view_rays(self.h, offset, count, _ptr(out)))
+        return out
+
+    def rng_stream(self, pixel, sample, stream, n):
+        out = np.zeros(n, np.uint32)
+        self._check(self.lib.ptgpu_rng_stream(self.h, pixel, sample, stream, n, _ptr(out)))
+        return out
+
+    # ------------------------------------------------------------------ statistics
+    def stats(self):
+        st = PtStats()
+        self._check(self.lib.ptgpu_get_stats(self.h, C.byref(st)))
+        return st
+
+    def reset_stats(self):
+        self._check(self.lib.ptgpu_reset_stats(self.h))
+
+    # ------------------------------------------------------------------ device-memory plumbing (torch)
+    def bind_accumulator(self, tensor):
+        """tensor: contiguous float32 CUDA tensor with width*height*4 elements (sum.rgb, n)."""
+        nbytes = tensor.numel() * tensor.element_size()
+        self._check(self.lib.ptgpu_bind_accumulator(self.h, C.c_void_p(tensor.data_ptr()), nbytes))
+        self._acc_keepalive = tensor
+
+    def set_stream(self, stream_ptr):
+        self._check(self.lib.ptgpu_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+
+def pixels_from_accumulator(acc):
+    """(sum.rgb, n) rows -> Pixel records with color = sum / n (rendering.d:483)."""
+    acc = np.asarray(acc, np.float32).reshape(-1, 4)
+    out = np.zeros(len(acc), PIXEL_DTYPE)
+    out['sum'] = acc[:, :3]; out['n'] = acc[:, 3]
+    nz = acc[:, 3] > 0
+    out['color'][nz] = acc[nz, :3] / acc[nz, 3:4]
+    return out

@@ -1,0 +1,678 @@
+// C ABI of libptgpu (include/ptgpu.h): handle, scene upload, wavefront scheduling, read-back.
+#include "../../include/ptgpu.h"
+#include "kernels.h"
+#include "scene_host.h"
+#include "thmodel.h"
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace pt;
+
+namespace {
+
+thread_local std::string g_err;
+
+struct ApiError { int code; std::string msg; };
+[[noreturn]] void fail(int code, const std::string& m) { throw ApiError{code, m}; }
+
+#define HIPCHECK(expr)                                                                                        \
+  do {                                                                                                        \
+    hipError_t e_ = (expr);                                                                                   \
+    if (e_ != hipSuccess) fail(PT_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr; size_t bytes = 0;
+  void alloc(size_t n) {
+    if (n <= bytes && p) return;
+    release();
+    if (n == 0) n = 16;
+    hipError_t e = hipMalloc(&p, n);
+    if (e != hipSuccess) { p = nullptr; fail(PT_E_NOMEM, "hipMalloc(" + std::to_string(n) + " bytes): " + hipGetErrorString(e)); }
+    bytes = n;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+  ~DevBuf() { release(); }
+  template <typename T> T* as() const { return (T*)p; }
+};
+
+struct EventPair { hipEvent_t a, b; int kind; };
+constexpr int KIND_RENDER = PT_K_COUNT;       // span of one ptgpu_render call
+constexpr size_t MAX_EVENT_PAIRS = 16384;
+
+}  // namespace
+
+struct PtHandle {
+  PtConfig cfg{};
+  int numCUs = 256;
+  hipStream_t stream = nullptr; bool ownStream = false;
+  bool haveScene = false, haveCamera = false;
+  Camera cam{};
+  FlatScene flat; LightTable lights; Bvh bvh;
+  DevBuf dNodes, dTris, dNrm, dMats, dLights, dLightFirst, dLightCount, dLightArea;
+  DevScene dsc{};
+  DevBuf accOwn; float4* acc = nullptr; uint64_t accBytes = 0;
+  // wavefront buffers
+  DevBuf bHit, bRayO[2], bRayD[2], bLacc, bThr, bRng, bShO, bShD, bShW, bCounters, bStats;
+  Wavefront wf{}; uint32_t wfKinds = 0, wfRounds = 0;
+  // statistics
+  PtStats st{};
+  std::vector<EventPair> pending; std::vector<hipEvent_t> freeEvents;
+  bool eventOverflow = false;
+};
+
+namespace {
+
+// device < 0 makes a host-only handle: scene preparation (reader, flattening, lights, BVH) works, anything
+// that needs the GPU fails.
+void useDevice(PtHandle* h) {
+  if (h->cfg.device < 0) fail(PT_E_DEVICE, "this handle was created without a device (device < 0): host-side scene preparation only");
+  HIPCHECK(hipSetDevice(h->cfg.device));
+}
+
+void normalizeConfig(PtConfig& c) {
+  if (c.floatEpsilon == 0.0f) c.floatEpsilon = 1e-5f;
+  if (c.rrProb == 0.0f) c.rrProb = 0.7f;
+  if (c.maxDepth == 0) c.maxDepth = 5;
+  if (c.numIndirect == 0) c.numIndirect = 5;
+  if (c.maxLeafTris == 0) c.maxLeafTris = 4;
+  if (c.maxLeafTris > BVH_MAX_LEAF) c.maxLeafTris = BVH_MAX_LEAF;
+}
+
+void validateConfig(const PtConfig& c) {
+  if (c.width == 0 || c.height == 0) fail(PT_E_INVALID, "width and height must be non-zero");
+  if ((uint64_t)c.width * c.height > 0x7FFFFFFFull) fail(PT_E_INVALID, "frame has more than 2^31 pixels");
+  if (c.mode > 1) fail(PT_E_INVALID, "mode must be 0 (direct only) or 1 (+ indirect chains)");
+  if (c.numIndirect > 64) fail(PT_E_INVALID, "numIndirect > 64");
+  if (c.maxDepth > 64) fail(PT_E_INVALID, "maxDepth > 64");
+}
+
+DevCfg makeDevCfg(const PtHandle* h) {
+  const PtConfig& c = h->cfg; DevCfg d;
+  d.W = c.width; d.H = c.height; d.mode = c.mode; d.hasSky = c.hasSky; d.hasLights = c.hasLights;
+  d.sunDir = v3(c.sunDir[0], c.sunDir[1], c.sunDir[2]);
+  d.sunRadiance = v3(c.sunRadiance[0], c.sunRadiance[1], c.sunRadiance[2]);
+  d.skyRadiance = v3(c.skyRadiance[0], c.skyRadiance[1], c.skyRadiance[2]);
+  d.eps = c.floatEpsilon; d.rrProb = c.rrProb; d.maxDepth = c.maxDepth; d.numIndirect = c.numIndirect;
+  d.seed = c.seed; d.sampleBase = c.sampleBase; d.cam = h->cam;
+  return d;
+}
+
+LaunchCfg makeLaunchCfg(const PtHandle* h) {
+  return LaunchCfg{h->numCUs, (h->cfg.flags & PT_FLAG_COUNT_VISITS) != 0, h->stream};
+}
+
+hipEvent_t getEvent(PtHandle* h) {
+  if (!h->freeEvents.empty()) { hipEvent_t e = h->freeEvents.back(); h->freeEvents.pop_back(); return e; }
+  hipEvent_t e; HIPCHECK(hipEventCreate(&e)); return e;
+}
+
+// Brackets a launch with events when asked to; the pairs are resolved in ptgpu_get_stats.
+struct Timed {
+  PtHandle* h; int kind; bool on; hipEvent_t a{}, b{};
+  Timed(PtHandle* h_, int kind_, bool force = false) : h(h_), kind(kind_) {
+    on = (force || (h->cfg.flags & PT_FLAG_TIME_KERNELS)) && h->pending.size() < MAX_EVENT_PAIRS;
+    if (!on && (force || (h->cfg.flags & PT_FLAG_TIME_KERNELS))) h->eventOverflow = true;
+    if (on) { a = getEvent(h); b = getEvent(h); HIPCHECK(hipEventRecord(a, h->stream)); }
+    if (kind < PT_K_COUNT) h->st.kernelLaunches[kind]++;
+  }
+  void done() { if (on) { HIPCHECK(hipEventRecord(b, h->stream)); h->pending.push_back(EventPair{a, b, kind}); on = false; } }
+};
+
+void resolveEvents(PtHandle* h) {
+  for (EventPair& p : h->pending) {
+    float ms = 0.0f;
+    HIPCHECK(hipEventSynchronize(p.b));
+    HIPCHECK(hipEventElapsedTime(&ms, p.a, p.b));
+    if (p.kind == KIND_RENDER) h->st.renderMs += ms; else h->st.kernelMs[p.kind] += ms;
+    h->freeEvents.push_back(p.a); h->freeEvents.push_back(p.b);
+  }
+  h->pending.clear();
+}
+
+void uploadScene(PtHandle* h) {
+  const FlatScene& fs = h->flat;
+  uint32_t T = (uint32_t)fs.numTriangles();
+  if (T >= (1u << BVH_COUNT_SHIFT)) fail(PT_E_INVALID, "too many triangles (limit 2^28 - 1)");
+  for (uint32_t i = 0; i < T; i++)
+    if (fs.matIdx[i] >= fs.mats.size()) fail(PT_E_INVALID, "material index out of range at triangle " + std::to_string(i));
+  findLights(fs, h->lights);
+  if (h->lights.numGroups() + 2 > (size_t)PT_MAX_KINDS)
+    fail(PT_E_INVALID, "more than " + std::to_string(PT_MAX_KINDS - 2) + " emissive materials");
+  buildBvh(fs.v.data(), T, h->cfg.maxLeafTris, h->bvh);
+  const Bvh& bvh = h->bvh;
+
+  // triangles in leaf order: (v0, origId) (v2 - v0) (v1 - v0)
+  uint32_t NT = (uint32_t)bvh.triOrder.size();
+  std::vector<float> tris((size_t)NT * 12, 0.0f);
+  for (uint32_t i = 0; i < NT; i++) {
+    uint32_t o = bvh.triOrder[i];
+    float* r = &tris[(size_t)i * 12];
+    if (o == 0xFFFFFFFFu) { std::memcpy(&r[3], &o, 4); continue; }
+    const float* p = &fs.v[(size_t)o * 9];
+    r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; std::memcpy(&r[3], &o, 4);
+    r[4] = p[6] - p[0]; r[5] = p[7] - p[1]; r[6] = p[8] - p[2];
+    r[8] = p[3] - p[0]; r[9] = p[4] - p[1]; r[10] = p[5] - p[2];
+  }
+  std::vector<float> nrm((size_t)std::max(1u, T) * 12, 0.0f);
+  for (uint32_t i = 0; i < T; i++) {
+    float* r = &nrm[(size_t)i * 12]; const float* q = &fs.n[(size_t)i * 9];
+    for (int k = 0; k < 3; k++) { r[4 * k] = q[3 * k]; r[4 * k + 1] = q[3 * k + 1]; r[4 * k + 2] = q[3 * k + 2]; }
+    uint32_t m = fs.matIdx[i]; std::memcpy(&r[3], &m, 4);
+  }
+  std::vector<float> mats(std::max<size_t>(1, fs.mats.size()) * 4, 0.0f);
+  for (size_t i = 0; i < fs.mats.size(); i++) {
+    mats[4 * i] = fs.mats[i].emissive; mats[4 * i + 1] = fs.mats[i].color[0];
+    mats[4 * i + 2] = fs.mats[i].color[1]; mats[4 * i + 3] = fs.mats[i].color[2];
+  }
+  const LightTable& lt = h->lights;
+  std::vector<float> lights(std::max<size_t>(1, lt.tris.size()) * 12, 0.0f);
+  for (size_t i = 0; i < lt.tris.size(); i++) std::memcpy(&lights[i * 12], &lt.tris[i], 44);
+  std::vector<uint32_t> lf(lt.first), lc(lt.count); std::vector<float> la(lt.totalArea);
+  if (lf.empty()) { lf.push_back(0); lc.push_back(0); la.push_back(0.0f); }
+
+  h->st.numTriangles = T; h->st.numNodes = bvh.numNodes; h->st.bvhDepth = bvh.depth;
+  h->st.numLightGroups = (uint32_t)lt.numGroups();
+  if (h->cfg.device < 0) { h->haveScene = true; return; }
+  auto up = [&](DevBuf& b, const void* src, size_t bytes) {
+    b.alloc(bytes);
+    HIPCHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+  };
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  up(h->dNodes, bvh.nodes.data(), bvh.nodes.size() * 4);
+  up(h->dTris, tris.data(), tris.size() * 4);
+  up(h->dNrm, nrm.data(), nrm.size() * 4);
+  up(h->dMats, mats.data(), mats.size() * 4);
+  up(h->dLights, lights.data(), lights.size() * 4);
+  up(h->dLightFirst, lf.data(), lf.size() * 4);
+  up(h->dLightCount, lc.data(), lc.size() * 4);
+  up(h->dLightArea, la.data(), la.size() * 4);
+
+  DevScene& d = h->dsc;
+  d.nodes = h->dNodes.as<float4>(); d.tris = h->dTris.as<float4>(); d.nrm = h->dNrm.as<float4>();
+  d.mats = h->dMats.as<float4>(); d.lights = h->dLights.as<float>();
+  d.lightFirst = h->dLightFirst.as<uint32_t>(); d.lightCount = h->dLightCount.as<uint32_t>();
+  d.lightArea = h->dLightArea.as<float>();
+  d.numNodes = bvh.numNodes; d.numTris = NT; d.numOrigTris = T; d.rootRef = bvh.rootRef;
+  d.numLightGroups = (uint32_t)lt.numGroups();
+  size_t ldsNeed = ((size_t)2 * bvh.numNodes + (size_t)3 * NT) * 16;
+  d.ldsBytes = (!(h->cfg.flags & PT_FLAG_NO_LDS_SCENE) && ldsNeed <= 156 * 1024) ? (uint32_t)ldsNeed : 0;
+  h->haveScene = true;
+  h->st.numTriangles = T; h->st.numNodes = bvh.numNodes; h->st.bvhDepth = bvh.depth;
+  h->st.numLightGroups = d.numLightGroups; h->st.sceneInLds = d.ldsBytes ? 1 : 0;
+}
+
+uint32_t numKinds(const PtHandle* h) { return h->dsc.numLightGroups + 2; }
+
+void ensureWavefront(PtHandle* h) {
+  const PtConfig& c = h->cfg;
+  uint32_t capSlots = c.batchSlots ? c.batchSlots : (c.mode == 1 ? (1u << 20) : (1u << 22));
+  uint64_t frame = (uint64_t)c.width * c.height;
+  // no point in more slots than 64 samples of the whole frame
+  capSlots = (uint32_t)std::max<uint64_t>(1024, std::min<uint64_t>(capSlots, frame * 64));
+  uint32_t NI = c.mode == 1 ? c.numIndirect : 0;
+  uint32_t lanes = 1 + NI;
+  uint64_t capQueue = (uint64_t)capSlots * std::max(1u, NI);
+  if (capQueue > 0x7FFFFFFFull) fail(PT_E_INVALID, "batchSlots * numIndirect too large");
+  uint32_t kinds = numKinds(h), rounds = c.mode == 1 ? c.maxDepth + 3 : 1;
+  Wavefront& w = h->wf;
+  if (w.capSlots == capSlots && w.capQueue == (uint32_t)capQueue && w.lanes == lanes && h->wfKinds == kinds && h->wfRounds == rounds) return;
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  h->bHit.alloc(capQueue * 16);
+  for (int q = 0; q < 2; q++) { h->bRayO[q].alloc(NI ? capQueue * 16 : 16); h->bRayD[q].alloc(NI ? capQueue * 16 : 16); }
+  h->bLacc.alloc((uint64_t)lanes * capSlots * 16);
+  h->bThr.alloc(NI ? (uint64_t)lanes * capSlots * 16 : 16);
+  h->bRng.alloc(NI ? (uint64_t)lanes * capSlots * 8 : 16);
+  h->bShO.alloc((uint64_t)kinds * capQueue * 16);
+  h->bShD.alloc((uint64_t)kinds * capQueue * 16);
+  h->bShW.alloc((uint64_t)kinds * capQueue * 16);
+  h->bCounters.alloc((size_t)rounds * PT_COUNTER_SET * 4);
+  w.hit = h->bHit.as<float4>();
+  for (int q = 0; q < 2; q++) { w.rayO[q] = h->bRayO[q].as<float4>(); w.rayD[q] = h->bRayD[q].as<float4>(); }
+  w.Lacc = h->bLacc.as<float4>(); w.thr = h->bThr.as<float4>(); w.rng = h->bRng.as<uint2>();
+  w.shO = h->bShO.as<float4>(); w.shD = h->bShD.as<float4>(); w.shW = h->bShW.as<float4>();
+  w.stats = h->bStats.as<unsigned long long>();
+  w.capSlots = capSlots; w.capQueue = (uint32_t)capQueue; w.lanes = lanes;
+  h->wfKinds = kinds; h->wfRounds = rounds;
+}
+
+// Shadow rays of one vertex generation: light groups by Scene.trace, sun and sky by Scene.hitsNothing.
+void launchShadowKinds(PtHandle* h, const LaunchCfg& lc, const DevCfg& dc, const Wavefront& wf) {
+  int kind = 0;
+  if (dc.hasLights)
+    for (uint32_t li = 0; li < h->dsc.numLightGroups; li++, kind++) {
+      Timed t(h, PT_K_CONNECT); launchConnect(lc, h->dsc, dc, wf, kind, h->lights.totalArea[li]); t.done();
+    }
+  if (dc.hasSky)
+    for (int s = 0; s < 2; s++, kind++) { Timed t(h, PT_K_OCCLUDED); launchOccluded(lc, h->dsc, dc, wf, kind); t.done(); }
+}
+
+// One wavefront batch: npix pixels x k samples.
+void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm) {
+  Wavefront wf = h->wf;
+  uint32_t* counters = h->bCounters.as<uint32_t>();
+  uint32_t nslots = pm.npix * pm.k;
+  HIPCHECK(hipMemsetAsync(counters, 0, (size_t)h->wfRounds * PT_COUNTER_SET * 4, h->stream));
+  wf.cntIn = counters; wf.cntOut = counters;          // round 0 writes set 0
+  { Timed t(h, PT_K_EXTEND); launchExtendPrimary(lc, h->dsc, dc, pm, h->acc, nslots, 1, wf.hit, wf.stats); t.done(); }
+  { Timed t(h, PT_K_SHADE); launchShade(lc, h->dsc, dc, pm, h->acc, wf, true, nslots, 0, 0); t.done(); }
+  launchShadowKinds(h, lc, dc, wf);
+  h->st.raysPrimary += nslots; h->st.samples += nslots;
+  if (dc.mode == 1) {
+    // depth 0..maxDepth can still spawn a ray (the check is depth > maxDepth, rendering.d:380)
+    for (uint32_t round = 0; round <= dc.maxDepth; round++) {
+      int qIn = round & 1, qOut = qIn ^ 1;
+      wf.cntIn = counters + (size_t)round * PT_COUNTER_SET;
+      wf.cntOut = counters + (size_t)(round + 1) * PT_COUNTER_SET;
+      { Timed t(h, PT_K_EXTEND); launchExtendQueue(lc, h->dsc, dc, wf, qIn, STAT_RAYS_INDIRECT); t.done(); }
+      { Timed t(h, PT_K_SHADE); launchShade(lc, h->dsc, dc, pm, h->acc, wf, false, 0, qIn, qOut); t.done(); }
+      launchShadowKinds(h, lc, dc, wf);
+    }
+  }
+  { Timed t(h, PT_K_ACCUM); launchAccumulate(lc, dc, pm, h->acc, wf); t.done(); }
+  HIPCHECK(hipGetLastError());
+}
+
+void renderPixels(PtHandle* h, PixMap base, uint64_t totalPix, uint32_t spp) {
+  if (!h->haveScene) fail(PT_E_STATE, "no scene: call ptgpu_upload_scene or ptgpu_load_thmodel first");
+  if (!h->haveCamera) fail(PT_E_STATE, "no camera: call ptgpu_set_camera or ptgpu_camera_look_at first");
+  if (totalPix == 0 || spp == 0) return;
+  ensureWavefront(h);
+  DevCfg dc = makeDevCfg(h); LaunchCfg lc = makeLaunchCfg(h);
+  Timed span(h, KIND_RENDER, true);
+  uint32_t cap = h->wf.capSlots;
+  for (uint64_t lp0 = 0; lp0 < totalPix; lp0 += cap) {
+    uint32_t npix = (uint32_t)std::min<uint64_t>(cap, totalPix - lp0);
+    uint32_t kmax = std::max(1u, cap / npix);
+    for (uint32_t s0 = 0; s0 < spp; s0 += kmax) {
+      PixMap pm = base; pm.lpBase = (uint32_t)lp0; pm.npix = npix; pm.k = std::min(kmax, spp - s0);
+      renderBatch(h, dc, lc, pm);
+    }
+  }
+  span.done();
+}
+
+void checkWindow(const PtHandle* h, uint32_t off, uint32_t count) {
+  uint64_t frame = (uint64_t)h->cfg.width * h->cfg.height;
+  if ((uint64_t)off + count > frame) fail(PT_E_INVALID, "pixel window [" + std::to_string(off) + ", +" + std::to_string(count) + ") exceeds the frame");
+}
+
+template <typename F> int guarded(F&& f) {
+  try { f(); return PT_OK; }
+  catch (const ApiError& e) { g_err = e.msg; return e.code; }
+  catch (const IoError& e) { g_err = e.what(); return PT_E_IO; }
+  catch (const std::bad_alloc&) { g_err = "out of host memory"; return PT_E_NOMEM; }
+  catch (const std::exception& e) { g_err = e.what(); return PT_E_INVALID; }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ptgpu_last_error(void) { return g_err.c_str(); }
+
+int ptgpu_create(const PtConfig* cfg, PtHandle** out) {
+  if (out) *out = nullptr;
+  PtHandle* h = nullptr;
+  int rc = guarded([&]() {
+    if (!cfg || !out) fail(PT_E_INVALID, "null argument");
+    PtConfig c = *cfg; normalizeConfig(c); validateConfig(c);
+    if (c.device < 0) { h = new PtHandle(); h->cfg = c; h->accBytes = (uint64_t)c.width * c.height * 16; return; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) fail(PT_E_DEVICE, std::string("no HIP device available: ") + hipGetErrorString(e));
+    if (c.device >= ndev) fail(PT_E_INVALID, "device ordinal " + std::to_string(c.device) + " out of range");
+    h = new PtHandle(); h->cfg = c;
+    useDevice(h);
+    hipDeviceProp_t prop; HIPCHECK(hipGetDeviceProperties(&prop, c.device));
+    h->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIPCHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->ownStream = true;
+    h->accBytes = (uint64_t)c.width * c.height * 16;
+    h->accOwn.alloc(h->accBytes); h->acc = h->accOwn.as<float4>();
+    HIPCHECK(hipMemset(h->acc, 0, h->accBytes));
+    h->bStats.alloc(STAT_COUNT * 8); HIPCHECK(hipMemset(h->bStats.p, 0, STAT_COUNT * 8));
+  });
+  if (rc != PT_OK) { delete h; return rc; }
+  *out = h; return PT_OK;
+}
+
+int ptgpu_destroy(PtHandle* h) {
+  if (!h) return PT_OK;
+  return guarded([&]() {
+    if (h->cfg.device < 0) { delete h; return; }
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (EventPair& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (hipEvent_t e : h->freeEvents) (void)hipEventDestroy(e);
+    if (h->ownStream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+  });
+}
+
+int ptgpu_set_config(PtHandle* h, const PtConfig* cfg) {
+  return guarded([&]() {
+    if (!h || !cfg) fail(PT_E_INVALID, "null argument");
+    PtConfig c = *cfg; normalizeConfig(c); validateConfig(c);
+    if (c.device != h->cfg.device || c.width != h->cfg.width || c.height != h->cfg.height || c.batchSlots != h->cfg.batchSlots)
+      fail(PT_E_INVALID, "device, width, height and batchSlots are fixed at ptgpu_create");
+    bool rebuild = c.maxLeafTris != h->cfg.maxLeafTris || ((c.flags ^ h->cfg.flags) & PT_FLAG_NO_LDS_SCENE);
+    h->cfg = c;
+    if (rebuild && h->haveScene) { if (h->cfg.device >= 0) useDevice(h); uploadScene(h); }
+  });
+}
+
+int ptgpu_upload_scene(PtHandle* h, const float* v, const float* n, const uint32_t* matIdx, const PtMaterial* mats,
+                       uint32_t T, uint32_t M) {
+  return guarded([&]() {
+    if (!h) fail(PT_E_INVALID, "null handle");
+    if (T && (!v || !n || !matIdx)) fail(PT_E_INVALID, "null triangle array");
+    if (M == 0 || !mats) fail(PT_E_INVALID, "at least one material is required");
+    if (h->cfg.device >= 0) useDevice(h);
+    FlatScene fs;
+    fs.v.assign(v, v + (size_t)T * 9); fs.n.assign(n, n + (size_t)T * 9);
+    fs.matIdx.assign(matIdx, matIdx + T); fs.mats.assign(mats, mats + M); fs.matNames.assign(M, "");
+    h->flat = std::move(fs);
+    uploadScene(h);
+  });
+}
+
+int ptgpu_load_thmodel(PtHandle* h, const char* path, int materialTable, const float* modelMatrix) {
+  return guarded([&]() {
+    if (!h || !path) fail(PT_E_INVALID, "null argument");
+    if (materialTable != 0 && materialTable != 1) fail(PT_E_INVALID, "materialTable must be 0 or 1");
+    if (h->cfg.device >= 0) useDevice(h);
+    ModelData model; LoadFile(path, model);
+    FlatScene fs; flattenModel(model, materialTable, modelMatrix, fs);
+    h->flat = std::move(fs);
+    uploadScene(h);
+  });
+}
+
+int ptgpu_get_scene(PtHandle* h, float* v, float* n, uint32_t* matIdx, PtMaterial* mats, uint32_t* numMaterials) {
+  return guarded([&]() {
+    if (!h) fail(PT_E_INVALID, "null handle");
+    if (!h->haveScene) fail(PT_E_STATE, "no scene");
+    const FlatScene& fs = h->flat;
+    if (v) std::memcpy(v, fs.v.data(), fs.v.size() * 4);
+    if (n) std::memcpy(n, fs.n.data(), fs.n.size() * 4);
+    if (matIdx) std::memcpy(matIdx, fs.matIdx.data(), fs.matIdx.size() * 4);
+    if (mats) std::memcpy(mats, fs.mats.data(), fs.mats.size() * sizeof(PtMaterial));
+    if (numMaterials) *numMaterials = (uint32_t)fs.mats.size();
+  });
+}
+
+int ptgpu_get_light_group(PtHandle* h, uint32_t g, float* rows11, uint32_t cap, uint32_t* count, float* totalArea) {
+  return guarded([&]() {
+    if (!h) fail(PT_E_INVALID, "null handle");
+    if (!h->haveScene) fail(PT_E_STATE, "no scene");
+    if (g >= h->lights.numGroups()) fail(PT_E_INVALID, "light group out of range");
+    uint32_t c = h->lights.count[g];
+    if (rows11) for (uint32_t i = 0; i < c && i < cap; i++) std::memcpy(rows11 + 11 * (size_t)i, &h->lights.tris[h->lights.first[g] + i], 44);
+    if (count) *count = c;
+    if (totalArea) *totalArea = h->lights.totalArea[g];
+  });
+}
+
+int ptgpu_get_bvh(PtHandle* h, float* nodes8, uint32_t* triOrder) {
+  return guarded([&]() {
+    if (!h) fail(PT_E_INVALID, "null handle");
+    if (!h->haveScene) fail(PT_E_STATE, "no scene");
+    if (nodes8) std::memcpy(nodes8, h->bvh.nodes.data(), h->bvh.nodes.size() * 4);
+    if (triOrder) std::memcpy(triOrder, h->bvh.triOrder.data(), h->bvh.triOrder.size() * 4);
+  });
+}
+
+int ptgpu_set_camera(PtHandle* h, const float pos[3], const float dir[3], const float right[3], const float up[3],
+                     float tanFov, float aspect) {
+  return guarded([&]() {
+    if (!h || !pos || !dir || !right || !up) fail(PT_E_INVALID, "null argument");
+    h->cam.pos = v3(pos[0], pos[1], pos[2]); h->cam.dir = v3(dir[0], dir[1], dir[2]);
+    h->cam.right = v3(right[0], right[1], right[2]); h->cam.up = v3(up[0], up[1], up[2]);
+    h->cam.tanFov = tanFov; h->cam.aspect = aspect; h->haveCamera = true;
+  });
+}
+
+int ptgpu_camera_look_at(PtHandle* h, float fovDegrees, float aspect, const float from[3], const float to[3],
+                         const float up[3], float* out14) {
+  return guarded([&]() {
+    if (!from || !to || !up) fail(PT_E_INVALID, "null argument");
+    Camera c = cameraLookAt(fovDegrees, aspect, v3(from[0], from[1], from[2]), v3(to[0], to[1], to[2]), v3(up[0], up[1], up[2]));
+    if (h) { h->cam = c; h->haveCamera = true; }
+    if (out14) {
+      float r[14] = {c.pos.x, c.pos.y, c.pos.z, c.dir.x, c.dir.y, c.dir.z, c.right.x, c.right.y, c.right.z,
+                     c.up.x, c.up.y, c.up.z, c.tanFov, c.aspect};
+      std::memcpy(out14, r, sizeof(r));
+    }
+  });
+}
+
+int ptgpu_render(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount, uint32_t spp) {
+  return guarded([&]() {
+    if (!h) fail(PT_E_INVALID, "null handle");
+    checkWindow(h, pixelOffset, pixelCount);
+    useDevice(h);
+    PixMap pm{}; pm.offset = pixelOffset;
+    renderPixels(h, pm, pixelCount, spp);
+  });
+}
+
+int ptgpu_render_bands(PtHandle* h, uint32_t bandRows, uint32_t bandFirst, uint32_t bandStride, uint32_t spp) {
+  return guarded([&]() {
+    if (!h) fail(PT_E_INVALID, "null handle");
+    if (bandRows == 0 || bandStride == 0 || bandFirst >= bandStride) fail(PT_E_INVALID, "need bandRows > 0 and bandFirst < bandStride");
+    useDevice(h);
+    uint32_t W = h->cfg.width, H = h->cfg.height;
+    uint32_t numBands = (H + bandRows - 1) / bandRows;
+    uint64_t rows = 0;
+    for (uint32_t b = bandFirst; b < numBands; b += bandStride) rows += std::min(bandRows, H - b * bandRows);
+    PixMap pm{}; pm.bandPix = bandRows * W; pm.bandFirst = bandFirst; pm.bandStride = bandStride;
+    renderPixels(h, pm, rows * W, spp);
+  });
+}
+
+int ptgpu_synchronize(PtHandle* h) {
+  return guarded([&]() {
+    if (!h) fail(PT_E_INVALID, "null handle");
+    useDevice(h);
+    HIPCHECK(hipStreamSynchronize(h->stream));
+  });
+}
+
+int ptgpu_read_pixels(PtHandle* h, uint32_t off, uint32_t count, PtPixel* out) {
+  return guarded([&]() {
+    if (!h || (!out && count)) fail(PT_E_INVALID, "null argument");
+    checkWindow(h, off, count); useDevice(h);
+    std::vector<float> tmp((size_t)count * 4);
+    HIPCHECK(hipMemcpyAsync(tmp.data(), h->acc + off, (size_t)count * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    for (uint32_t i = 0; i < count; i++) {
+      const float* a = &tmp[(size_t)i * 4]; PtPixel& p = out[i];
+      p.sum[0] = a[0]; p.sum[1] = a[1]; p.sum[2] = a[2]; p.n = a[3];
+      for (int k = 0; k < 3; k++) p.color[k] = a[3] > 0.0f ? a[k] / a[3] : 0.0f;     // pixel.color = pixel.sum / pixel.n
+    }
+  });
+}
+
+int ptgpu_write_pixels(PtHandle* h, uint32_t off, uint32_t count, const PtPixel* in) {
+  return guarded([&]() {
+    if (!h || (!in && count)) fail(PT_E_INVALID, "null argument");
+    checkWindow(h, off, count); useDevice(h);
+    std::vector<float> tmp((size_t)count * 4);
+    for (uint32_t i = 0; i < count; i++) { tmp[4 * (size_t)i] = in[i].sum[0]; tmp[4 * (size_t)i + 1] = in[i].sum[1];
+                                           tmp[4 * (size_t)i + 2] = in[i].sum[2]; tmp[4 * (size_t)i + 3] = in[i].n; }
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    HIPCHECK(hipMemcpy(h->acc + off, tmp.data(), (size_t)count * 16, hipMemcpyHostToDevice));
+  });
+}
+
+int ptgpu_clear_pixels(PtHandle* h) {
+  return guarded([&]() {
+    if (!h) fail(PT_E_INVALID, "null handle");
+    useDevice(h);
+    HIPCHECK(hipMemsetAsync(h->acc, 0, h->accBytes, h->stream));
+  });
+}
+
+int ptgpu_tonemap(PtHandle* h, uint32_t off, uint32_t count, uint8_t* rgb) {
+  return guarded([&]() {
+    if (!h || (!rgb && count)) fail(PT_E_INVALID, "null argument");
+    checkWindow(h, off, count); useDevice(h);
+    if (!count) return;
+    DevBuf d; d.alloc((size_t)count * 3);
+    launchTonemap(makeLaunchCfg(h), h->acc, off, count, d.as<uint8_t>());
+    HIPCHECK(hipMemcpyAsync(rgb, d.p, (size_t)count * 3, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+  });
+}
+
+int ptgpu_scene_trace(PtHandle* h, const float* rays6, uint32_t count, int32_t* triId, float* t, float* u, float* v, float* normal3) {
+  return guarded([&]() {
+    if (!h || (!rays6 && count)) fail(PT_E_INVALID, "null argument");
+    if (!h->haveScene) fail(PT_E_STATE, "no scene");
+    useDevice(h);
+    if (!count) return;
+    DevBuf dr, dtri, dt, du, dv, dn;
+    dr.alloc((size_t)count * 24); dtri.alloc((size_t)count * 4); dt.alloc((size_t)count * 4); du.alloc((size_t)count * 4);
+    dv.alloc((size_t)count * 4); dn.alloc((size_t)count * 12);
+    HIPCHECK(hipMemcpyAsync(dr.p, rays6, (size_t)count * 24, hipMemcpyHostToDevice, h->stream));
+    launchTraceRays(makeLaunchCfg(h), h->dsc, makeDevCfg(h), dr.as<float>(), count, dtri.as<int32_t>(), dt.as<float>(),
+                    du.as<float>(), dv.as<float>(), dn.as<float>());
+    HIPCHECK(hipGetLastError());
+    if (triId) HIPCHECK(hipMemcpyAsync(triId, dtri.p, (size_t)count * 4, hipMemcpyDeviceToHost, h->stream));
+    if (t) HIPCHECK(hipMemcpyAsync(t, dt.p, (size_t)count * 4, hipMemcpyDeviceToHost, h->stream));
+    if (u) HIPCHECK(hipMemcpyAsync(u, du.p, (size_t)count * 4, hipMemcpyDeviceToHost, h->stream));
+    if (v) HIPCHECK(hipMemcpyAsync(v, dv.p, (size_t)count * 4, hipMemcpyDeviceToHost, h->stream));
+    if (normal3) HIPCHECK(hipMemcpyAsync(normal3, dn.p, (size_t)count * 12, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+  });
+}
+
+int ptgpu_scene_hits_nothing(PtHandle* h, const float* rays6, uint32_t count, uint8_t* out) {
+  return guarded([&]() {
+    if (!h || ((!rays6 || !out) && count)) fail(PT_E_INVALID, "null argument");
+    if (!h->haveScene) fail(PT_E_STATE, "no scene");
+    useDevice(h);
+    if (!count) return;
+    DevBuf dr, dout; dr.alloc((size_t)count * 24); dout.alloc(count);
+    HIPCHECK(hipMemcpyAsync(dr.p, rays6, (size_t)count * 24, hipMemcpyHostToDevice, h->stream));
+    launchHitsNothing(makeLaunchCfg(h), h->dsc, makeDevCfg(h), dr.as<float>(), count, dout.as<uint8_t>());
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(out, dout.p, count, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+  });
+}
+
+int ptgpu_trace_primary(PtHandle* h, uint32_t off, uint32_t count, int32_t* triId, float* t, float* u, float* v) {
+  return guarded([&]() {
+    if (!h) fail(PT_E_INVALID, "null handle");
+    if (!h->haveScene) fail(PT_E_STATE, "no scene");
+    if (!h->haveCamera) fail(PT_E_STATE, "no camera");
+    checkWindow(h, off, count); useDevice(h);
+    if (!count) return;
+    DevBuf dh; dh.alloc((size_t)count * 16);
+    PixMap pm{}; pm.offset = off; pm.npix = count; pm.k = 1;
+    launchExtendPrimary(makeLaunchCfg(h), h->dsc, makeDevCfg(h), pm, h->acc, count, 0, dh.as<float4>(), h->bStats.as<unsigned long long>());
+    HIPCHECK(hipGetLastError());
+    std::vector<float> tmp((size_t)count * 4);
+    HIPCHECK(hipMemcpyAsync(tmp.data(), dh.p, (size_t)count * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    for (uint32_t i = 0; i < count; i++) {
+      const float* r = &tmp[(size_t)i * 4];
+      if (t) t[i] = r[0];
+      if (u) u[i] = r[1];
+      if (v) v[i] = r[2];
+      if (triId) { int32_t id; std::memcpy(&id, &r[3], 4); triId[i] = id; }
+    }
+  });
+}
+
+int ptgpu_view_rays(PtHandle* h, uint32_t off, uint32_t count, float* rays6) {
+  return guarded([&]() {
+    if (!h || (!rays6 && count)) fail(PT_E_INVALID, "null argument");
+    if (!h->haveCamera) fail(PT_E_STATE, "no camera");
+    checkWindow(h, off, count); useDevice(h);
+    if (!count) return;
+    DevBuf d; d.alloc((size_t)count * 24);
+    launchViewRays(makeLaunchCfg(h), makeDevCfg(h), off, count, d.as<float>());
+    HIPCHECK(hipMemcpyAsync(rays6, d.p, (size_t)count * 24, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+  });
+}
+
+int ptgpu_rng_stream(PtHandle* h, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n, uint32_t* out) {
+  return guarded([&]() {
+    if (!h || (!out && n)) fail(PT_E_INVALID, "null argument");
+    useDevice(h);
+    if (!n) return;
+    DevBuf d; d.alloc((size_t)n * 4);
+    launchRngStream(makeLaunchCfg(h), h->cfg.seed, pixel, sample, stream, n, d.as<uint32_t>());
+    HIPCHECK(hipMemcpyAsync(out, d.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+  });
+}
+
+int ptgpu_get_stats(PtHandle* h, PtStats* out) {
+  return guarded([&]() {
+    if (!h || !out) fail(PT_E_INVALID, "null argument");
+    if (h->cfg.device < 0) { *out = h->st; return; }
+    useDevice(h);
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    resolveEvents(h);
+    unsigned long long s[STAT_COUNT];
+    HIPCHECK(hipMemcpy(s, h->bStats.p, sizeof(s), hipMemcpyDeviceToHost));
+    h->st.raysLight = s[STAT_RAYS_LIGHT]; h->st.raysIndirect = s[STAT_RAYS_INDIRECT]; h->st.raysOcclusion = s[STAT_RAYS_OCCL];
+    h->st.nodesClosest = s[STAT_NODES_CLOSEST]; h->st.trisClosest = s[STAT_TRIS_CLOSEST];
+    h->st.nodesAny = s[STAT_NODES_ANY]; h->st.trisAny = s[STAT_TRIS_ANY];
+    *out = h->st;
+  });
+}
+
+int ptgpu_reset_stats(PtHandle* h) {
+  return guarded([&]() {
+    if (!h) fail(PT_E_INVALID, "null handle");
+    useDevice(h);
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    resolveEvents(h);
+    HIPCHECK(hipMemset(h->bStats.p, 0, STAT_COUNT * 8));
+    PtStats keep = h->st; h->st = PtStats();
+    h->st.numTriangles = keep.numTriangles; h->st.numNodes = keep.numNodes; h->st.bvhDepth = keep.bvhDepth;
+    h->st.numLightGroups = keep.numLightGroups; h->st.sceneInLds = keep.sceneInLds;
+    h->eventOverflow = false;
+  });
+}
+
+int ptgpu_bind_accumulator(PtHandle* h, void* devicePtr, uint64_t bytes) {
+  return guarded([&]() {
+    if (!h) fail(PT_E_INVALID, "null handle");
+    useDevice(h);
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    if (!devicePtr) { h->accOwn.alloc(h->accBytes); h->acc = h->accOwn.as<float4>(); return; }
+    if (bytes < h->accBytes) fail(PT_E_INVALID, "accumulator needs width*height*16 bytes");
+    if (((uintptr_t)devicePtr & 15) != 0) fail(PT_E_INVALID, "accumulator must be 16-byte aligned");
+    h->acc = (float4*)devicePtr;
+  });
+}
+
+int ptgpu_get_accumulator(PtHandle* h, void** devicePtr, uint64_t* bytes) {
+  return guarded([&]() {
+    if (!h) fail(PT_E_INVALID, "null handle");
+    if (devicePtr) *devicePtr = h->acc;
+    if (bytes) *bytes = h->accBytes;
+  });
+}
+
+int ptgpu_set_stream(PtHandle* h, void* hipStream) {
+  return guarded([&]() {
+    if (!h) fail(PT_E_INVALID, "null handle");
+    useDevice(h);
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    if (h->ownStream) { (void)hipStreamDestroy(h->stream); h->ownStream = false; }
+    h->stream = (hipStream_t)hipStream;
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,30 @@
+// Flattened acceleration structure for the traversal kernels.  Replaces the reference's pointer-linked
+// bounding-sphere tree (Scene.Node, scene.d:145-156; O(T^2) build at scene.d:457-500) with an
+// axis-aligned BVH2 laid out for the GPU: 32-byte nodes, sibling pairs adjacent, triangles in leaf order.
+#pragma once
+#include <stdint.h>
+#include <vector>
+
+namespace pt {
+
+// node = { min.xyz, ref, max.xyz, 0 } as 8 x 32-bit words.
+// ref: bits 31..28 = triangle count (0 => internal), bits 27..0 = pair index of the two children
+// (children are nodes 2*pair and 2*pair+1) or index of the leaf's first triangle in leaf order.
+constexpr uint32_t BVH_COUNT_SHIFT = 28;
+constexpr uint32_t BVH_INDEX_MASK = (1u << BVH_COUNT_SHIFT) - 1;
+constexpr uint32_t BVH_MAX_LEAF = 15;
+constexpr uint32_t BVH_MAX_DEPTH = 60;       // the kernels' traversal stack holds 64 entries
+
+struct Bvh {
+  std::vector<float> nodes;          // numNodes x 8 (node 1 is padding so that pairs stay aligned)
+  std::vector<uint32_t> triOrder;    // original triangle id per leaf-order slot (degenerate triangles dropped)
+  uint32_t rootRef = 0;
+  uint32_t depth = 0;
+  uint32_t numNodes = 0;
+  double buildSeconds = 0;
+};
+
+// v = T x 9 floats (v0, v1, v2).  Binned-SAH top-down build, leaves of at most maxLeaf triangles.
+void buildBvh(const float* v, uint32_t T, uint32_t maxLeaf, Bvh& out);
+
+}  // namespace pt

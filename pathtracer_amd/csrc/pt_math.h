@@ -1,0 +1,127 @@
+// Arithmetic shared by the host layer and the gfx950 kernels.
+//
+// The reference does all of its vector arithmetic through thBase (vec3, Ray, Triangle, Plane,
+// mat3/mat4, FloatEpsilon, fastsqrt), which is not part of the reference checkout.  Every operation
+// here therefore has one fixed evaluation order, written with explicit fmaf where a fused operation
+// is meant and compiled with -ffp-contract=off, so that host code, device code and any independent
+// CPU restatement produce the same bits for +,-,*,/ and sqrt:
+//   dot(a,b)      = fma(az,bz, fma(ay,by, ax*bx))
+//   cross(a,b).x  = fma(ay,bz, -(az*by))   (y, z cyclic)
+//   normalized(v) = v * (1 / sqrt(dot(v,v)))
+//   mat3(c0,c1,c2) * v = fma chain over columns
+// Anything else follows the reference source left to right, one rounding per operator.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#define PT_HD __host__ __device__ __forceinline__
+
+namespace pt {
+
+struct V3 { float x, y, z; };
+PT_HD V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_HD V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_HD V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_HD V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+PT_HD V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+PT_HD V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+PT_HD V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }   // component-wise (rendering.d:391,418,424)
+PT_HD V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+PT_HD float dot(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+PT_HD V3 cross(V3 a, V3 b) {
+  return v3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+PT_HD float length(V3 a) { return sqrtf(dot(a, a)); }
+PT_HD V3 normalized(V3 a) { float inv = 1.0f / sqrtf(dot(a, a)); return a * inv; }
+PT_HD V3 mat3cols(V3 c0, V3 c1, V3 c2, V3 v) {
+  return v3(fmaf(c2.x, v.z, fmaf(c1.x, v.y, c0.x * v.x)),
+            fmaf(c2.y, v.z, fmaf(c1.y, v.y, c0.y * v.x)),
+            fmaf(c2.z, v.z, fmaf(c1.z, v.y, c0.z * v.x)));
+}
+
+#define PT_PI_F 3.14159265358979323846f
+#define PT_PI_2_F 1.57079632679489661923f
+#define PT_BRDF (1.0f / PT_PI_F)          /* rendering.d:368 */
+#define PT_FLT_MAX 3.402823466e+38f
+
+// Camera's state, camera.d:11-12
+struct Camera { V3 pos, dir, right, up; float tanFov, aspect; };
+
+// Camera.getScreenRay, camera.d:38-42
+PT_HD V3 screenRayDir(const Camera& c, float x, float y) {
+  V3 a = (c.right * x) * c.tanFov;
+  V3 b = ((c.up * y) * c.tanFov) * c.aspect;
+  return normalized((c.dir + a) + b);
+}
+
+// ------------------------------------------------------------------ RNG
+// Counter-keyed streams: (seed, pixel, sample, stream) -> xoroshiro64** state.  The reference uses one
+// Mt19937 per 4-scanline band (main.d:109,117), a serial dependence that cannot be kept on a GPU; keyed
+// streams make the image independent of how pixels are partitioned over wavefronts or GPUs.
+PT_HD uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+PT_HD uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15; return x;
+}
+struct Rng {
+  uint32_t s0, s1;
+  PT_HD void seed(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t stream) {
+    s0 = mix32(mix32(mix32(seed ^ 0x9E3779B9u) + pixel) ^ (sample * 0x85EBCA6Bu + stream));
+    s1 = mix32(mix32(mix32(seed ^ 0x7F4A7C15u) + sample) ^ (pixel * 0xC2B2AE35u + stream * 0x27D4EB2Fu));
+    if ((s0 | s1) == 0) s0 = 1;
+  }
+  PT_HD uint32_t next() {
+    uint32_t r = rotl32(s0 * 0x9E3779BBu, 5) * 5u;
+    s1 ^= s0; s0 = rotl32(s0, 26) ^ s1 ^ (s1 << 9); s1 = rotl32(s1, 13);
+    return r;
+  }
+  PT_HD float u01() { return (float)(next() >> 8) * (1.0f / 16777216.0f); }
+  PT_HD float uniform(float a, float b) { return a + (b - a) * u01(); }   // std.random.uniform, "[)"
+};
+
+// getViewRay's screen coordinates, rendering.d:280-283 (x first, then y)
+PT_HD void viewRayXY(uint32_t pixelIndex, uint32_t W, uint32_t H, Rng* gen, float& x, float& y) {
+  float psx = 1.0f / (float)W, psy = 1.0f / (float)H;
+  x = (float)(pixelIndex % W) / (float)W * 2.0f - 1.0f;
+  if (gen) x = x + gen->uniform(-psx, psx);
+  y = (float)(pixelIndex / W) / (float)H * 2.0f - 1.0f;
+  if (gen) y = y + gen->uniform(-psy, psy);
+}
+
+// Shading normal of Scene.trace, scene.d:711-723 (fastsqrt -> sqrtf).  u weights vertex 2, v vertex 1.
+PT_HD V3 interpNormal(V3 n0, V3 n1, V3 n2, float u, float v) {
+  float x = 1.0f / (u + v);
+  float u1 = x * u, v1 = x * v;
+  const float sqrt2 = 1.414213562f;
+  float d1 = sqrtf((1.0f - u1) * (1.0f - u1) + v1 * v1) / sqrt2;
+  float d2 = sqrtf(u1 * u1 + (1.0f - v1) * (1.0f - v1)) / sqrt2;
+  V3 interpolated1 = n1 * d1 + n2 * d2;
+  float len = sqrtf(u1 * u1 + v1 * v1);
+  float i1 = sqrtf(u * u + v * v) / len;
+  float i2 = 1.0f - i1;
+  return normalized(n0 * i2 + interpolated1 * i1);
+}
+
+// rendering.d:309-314
+PT_HD V3 angleToLocalDirection(float phi, float psi) {
+  float cosPhi = cosf(phi);
+  return v3(cosf(psi) * cosPhi, sinf(psi) * cosPhi, sinf(phi));
+}
+// rendering.d:316-330
+PT_HD V3 angleToDirection(float phi, float psi, V3 normal) {
+  float cosPhi = cosf(phi);
+  V3 localDir = v3(cosf(psi) * cosPhi, sinf(psi) * cosPhi, sinf(phi));
+  V3 up = normal, dir = v3(1, 0, 0);
+  if (fabsf(dot(dir, up)) > 0.9f) dir = v3(0, 1, 0);
+  V3 right = normalized(cross(up, dir));
+  dir = normalized(cross(up, right));
+  return mat3cols(dir, right, up, localDir);
+}
+// rendering.d:332-339 (its own sun direction (1,1,6), independent of g_sunDir)
+PT_HD V3 sampleSky(V3 dir) {
+  V3 sunDir = normalized(v3(1, 1, 6));
+  if (dot(sunDir, dir) > 0.997f) return v3(1.0f, 0.984f, 0.8f) * 30.0f;
+  return v3(0.682f, 0.977f, 1.0f);
+}
+
+}  // namespace pt
