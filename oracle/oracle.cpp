@@ -750,4 +750,54 @@ void orc_tonemap(const Pixel* pixels, uint32_t count, uint8_t* rgb) {
     }
 }
 
+// Traversal-cost model for the roofline: walks the PRODUCT's flattened BVH (nodes8 = {min.xyz, ref, max.xyz, 0},
+// ref = count << 28 | index, sibling pairs adjacent; triOrder = original triangle id per leaf slot) with the same
+// order as the kernels -- both children of a pair tested per step, near child first, far child stacked, boxes
+// culled against the closest accepted hit -- and counts box tests and triangle tests.  The kernels use the
+// hardware reciprocal for the slab test, this uses 1/x, so counts agree to a small fraction of a percent.
+// out = {nodes tested, triangles tested}; triId (optional) receives the accepted triangle (-1 = none).
+void orc_bvh_count(void* h, const float* nodes8, uint32_t rootRef, const uint32_t* triOrder, const float* rays6,
+                   uint32_t count, int anyHit, uint64_t* out, int32_t* triId) {
+  Scene* s = (Scene*)h; float eps = s->cfg.floatEpsilon;
+  uint64_t cN = 0, cT = 0;
+  for (uint32_t ri = 0; ri < count; ri++) {
+    const float* p = rays6 + 6 * (size_t)ri; Ray r{v3(p[0], p[1], p[2]), v3(p[3], p[4], p[5])};
+    float d[3] = {r.d.x, r.d.y, r.d.z}, o[3] = {r.o.x, r.o.y, r.o.z}, inv[3], oi[3];
+    for (int k = 0; k < 3; k++) { float dk = fabsf(d[k]) < 1e-20f ? copysignf(1e-20f, d[k]) : d[k]; inv[k] = 1.0f / dk; oi[k] = -o[k] * inv[k]; }
+    float bt = FLT_MAX; int btri = -1; uint32_t stack[64]; int sp = 0; uint32_t ref = rootRef; bool live = true, done = false;
+    auto slab = [&](const float* n, float& tn) {
+      float lo[3], hi[3];
+      for (int k = 0; k < 3; k++) { float a = std::fmaf(n[k], inv[k], oi[k]), b = std::fmaf(n[4 + k], inv[k], oi[k]); lo[k] = fminf(a, b); hi[k] = fmaxf(a, b); }
+      tn = fmaxf(fmaxf(lo[0], lo[1]), fmaxf(lo[2], 0.0f));
+      float tf = fminf(fminf(hi[0], hi[1]), hi[2]) * 1.0000005f;
+      return tn <= fminf(tf, bt);
+    };
+    while (live && !done) {
+      while ((ref >> 28) == 0) {
+        const float* n0 = nodes8 + (size_t)ref * 16; const float* n1 = n0 + 8; cN += 2;
+        float tn0, tn1; bool h0 = slab(n0, tn0), h1 = slab(n1, tn1);
+        uint32_t r0, r1; std::memcpy(&r0, n0 + 3, 4); std::memcpy(&r1, n1 + 3, 4);
+        if (h0 && h1) { bool sw = tn1 < tn0; stack[sp++] = sw ? r0 : r1; ref = sw ? r1 : r0; }
+        else if (h0 || h1) ref = h0 ? r0 : r1;
+        else { if (sp == 0) { live = false; break; } ref = stack[--sp]; }
+      }
+      if (!live) break;
+      uint32_t cnt = ref >> 28, first = ref & ((1u << 28) - 1);
+      for (uint32_t i = 0; i < cnt && !done; i++) {
+        uint32_t orig = triOrder[first + i]; cT++;
+        if (orig == 0xFFFFFFFFu) continue;
+        float pos = -1.0f, u = 0, v = 0, det;
+        if (triIntersects(s->tris[orig], r, eps, pos, u, v, det)) {
+          if (anyHit) { if (pos >= eps) { btri = (int)orig; done = true; } }
+          else if ((pos < bt || (pos == bt && (int)orig < btri)) && pos >= eps && det < 0.0f) { bt = pos; btri = (int)orig; }
+        }
+      }
+      if (sp == 0) break;
+      ref = stack[--sp];
+    }
+    if (triId) triId[ri] = btri;
+  }
+  out[0] = cN; out[1] = cT;
+}
+
 }  // extern "C"

@@ -54,6 +54,7 @@ def lib():
                                        C.c_uint32, C.c_int, C.c_void_p]
         L.orc_keyed_stream.argtypes = [C.c_uint32] * 5 + [C.c_void_p]
         L.orc_tonemap.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_bvh_count.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -148,6 +149,14 @@ class Oracle:
 
     def check_tree(self):
         return lib().orc_check_tree(self.h)
+
+    def bvh_count(self, nodes8, root_ref, tri_order, rays6, any_hit=False):
+        """Box/triangle tests the kernels' traversal order performs on the product's flattened BVH."""
+        nodes8 = np.ascontiguousarray(nodes8, np.float32); tri_order = np.ascontiguousarray(tri_order, np.uint32)
+        rays6 = np.ascontiguousarray(rays6, np.float32).reshape(-1, 6)
+        out = np.zeros(2, np.uint64); tri = np.empty(len(rays6), np.int32)
+        lib().orc_bvh_count(self.h, _p(nodes8), int(root_ref), _p(tri_order), _p(rays6), len(rays6), int(any_hit), _p(out), _p(tri))
+        return int(out[0]), int(out[1]), tri
 
     def render_mt(self, pixels, spp, nthreads=1, use_tree=True):
         """Reference-shaped renderer (bands + Mt19937).  Returns (seconds, counters[4])."""

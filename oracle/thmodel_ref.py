@@ -29,9 +29,13 @@ class _Cur:
         self.d, self.p, self.end = data, pos, len(data) if end is None else end
 
     def u8(self):
+        if self.p + 1 > len(self.d):
+            raise ValueError('truncated file')
         v = self.d[self.p]; self.p += 1; return v
 
     def u32(self):
+        if self.p + 4 > len(self.d):
+            raise ValueError('truncated file')
         v = struct.unpack_from('<I', self.d, self.p)[0]; self.p += 4; return v
 
     def raw(self, n):

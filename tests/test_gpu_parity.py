@@ -1,0 +1,181 @@
+"""GPU parity of the intersection path, through the C ABI, against the CPU oracle and the golden vectors.
+
+Bar: triangle ids bit-exact; t, u, v within 1e-5 (they are in fact bit-equal: both sides evaluate the same
+fixed sequence of fp32 operations); Scene.hitsNothing equal as booleans."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py
+import pathtracer_amd as P
+from conftest import CAMERAS, GOLDEN, make_oracle, make_tracer, model_path, soup
+
+pytestmark = pytest.mark.gpu
+NAMES = sorted(CAMERAS)
+TOL = 1e-5
+
+
+def assert_hits_equal(got, ref):
+    tri, t, u, v = got; otri, ot, ou, ov = ref
+    assert np.array_equal(tri, otri)                                  # integer ids: bit-exact
+    hit = otri >= 0
+    assert np.all(np.abs(t[hit] - ot[hit]) <= TOL * np.abs(ot[hit]))  # relative for t
+    assert np.all(np.abs(u[hit] - ou[hit]) <= TOL) and np.all(np.abs(v[hit] - ov[hit]) <= TOL)
+    assert np.array_equal(t[hit].view(np.uint32), ot[hit].view(np.uint32))   # stronger: same bits
+    assert np.array_equal(u[hit].view(np.uint32), ou[hit].view(np.uint32))
+    assert np.array_equal(v[hit].view(np.uint32), ov[hit].view(np.uint32))
+    assert (t[~hit] > 3e38).all()
+
+
+def test_rng_words_equal_oracle(require_gpu):
+    pt = P.PathTracer(8, 8, seed=2024)
+    g = np.load(os.path.join(GOLDEN, 'oracle_teapot_64x64.npz'))
+    assert np.array_equal(pt.rng_stream(17, 3, 1, 16), g['rng_words'])
+    for pixel, sample, stream in ((0, 0, 0), (123456, 77, 5), (2 ** 31 - 1, 2 ** 20, 1)):
+        assert np.array_equal(pt.rng_stream(pixel, sample, stream, 256), oracle_py.keyed_stream(2024, pixel, sample, stream, 256))
+
+
+@pytest.mark.parametrize('name,W,H', [('cornell-box', 512, 512), ('chest1', 640, 360), ('teapot', 1920, 1080)])
+def test_primary_hits_equal_exhaustive_oracle(require_gpu, name, W, H, flats):
+    """Full-frame probe without jitter (teapot at the 1920x1080 of the benchmark configuration)."""
+    pt = make_tracer(name, W, H)
+    o = make_oracle(flats[name], name, W, H)
+    assert np.array_equal(pt.view_rays().view(np.uint32), o.view_rays(0, W * H).view(np.uint32))   # rays bit-exact
+    got = pt.trace_primary()
+    ref = o.trace_primary(0, W * H, use_tree=False)
+    assert_hits_equal(got, ref)
+    assert (ref[0] >= 0).sum() > 0.15 * W * H
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_primary_hits_equal_golden(require_gpu, name):
+    g = np.load(os.path.join(GOLDEN, 'oracle_%s_64x64.npz' % name))
+    pt = make_tracer(name, 64, 64)
+    assert_hits_equal(pt.trace_primary(), (g['tri'], g['t'], g['u'], g['v']))
+
+
+def test_primary_window_and_offsets(require_gpu, flats):
+    W, H = 200, 120
+    pt = make_tracer('teapot', W, H); o = make_oracle(flats['teapot'], 'teapot', W, H)
+    for off, cnt in ((0, 1), (W * H - 1, 1), (777, 5003), (0, 0)):
+        got = pt.trace_primary(off, cnt)
+        if cnt:
+            assert_hits_equal(got, o.trace_primary(off, cnt, use_tree=False))
+        else:
+            assert len(got[0]) == 0
+    with pytest.raises(P.PtError):
+        pt.trace_primary(W * H - 2, 3)
+
+
+def random_rays(flat, n, seed):
+    rng = np.random.default_rng(seed)
+    pts = flat['v'].reshape(-1, 3)
+    lo, hi = pts.min(0), pts.max(0)
+    org = rng.uniform(lo - 0.3 * (hi - lo), hi + 0.3 * (hi - lo), (n, 3))
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, d], 1).astype(np.float32)
+    # a share of rays that start ON geometry (shadow / bounce rays do): origin = point on a triangle + tiny offset
+    k = n // 3
+    tri = rng.integers(0, len(flat['v']), k)
+    b = rng.dirichlet([1, 1, 1], k).astype(np.float32)
+    p = (flat['v'][tri] * b[:, :, None]).sum(1)
+    rays[:k, :3] = p + rays[:k, 3:] * np.float32(1e-5)
+    return rays
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_scene_trace_and_hits_nothing_on_random_rays(require_gpu, name, flats):
+    """Scene.trace (scene.d:681-743) and Scene.hitsNothing (scene.d:801-838) for arbitrary rays, inside and outside."""
+    pt = make_tracer(name, 16, 16)
+    o = make_oracle(flats[name], name, 16, 16)
+    rays = random_rays(flats[name], 60000, 42)
+    tri, t, u, v, nrm = pt.trace(rays)
+    ref = o.trace_rays(rays, kind=0, use_tree=False)
+    assert_hits_equal((tri, t, u, v), ref)
+    hit = np.flatnonzero(ref[0] >= 0)
+    assert len(hit) > 1000
+    for i in hit[:: max(1, len(hit) // 300)]:                          # interpolated shading normal, scene.d:711-723
+        en = o.interp_normal(ref[0][i], ref[2][i], ref[3][i])
+        assert np.allclose(nrm[i], en, atol=2e-6, equal_nan=True)
+    free = pt.hitsNothing(rays)
+    ofree = o.trace_rays(rays, kind=1, use_tree=False)[0] < 0
+    assert np.array_equal(free, ofree)
+    assert 0 < free.sum() < len(rays)
+
+
+def test_scene_traversed_from_global_memory_gives_the_same_hits(require_gpu, flats):
+    """PT_FLAG_NO_LDS_SCENE: the HBM/L2 variant of every traversal kernel against the LDS-staged one."""
+    name, W, H = 'teapot', 320, 180
+    a = make_tracer(name, W, H)
+    b = make_tracer(name, W, H, flags=P.PT_FLAG_NO_LDS_SCENE)
+    assert a.stats().sceneInLds == 1 and b.stats().sceneInLds == 0
+    for x, y in zip(a.trace_primary(), b.trace_primary()):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    rays = random_rays(flats[name], 20000, 1)
+    assert np.array_equal(a.hitsNothing(rays), b.hitsNothing(rays))
+
+
+@pytest.mark.parametrize('leaf', [1, 2, 8, 15])
+def test_hits_do_not_depend_on_the_tree(require_gpu, leaf, flats):
+    name, W, H = 'teapot', 256, 144
+    ref = make_oracle(flats[name], name, W, H).trace_primary(0, W * H, use_tree=False)
+    pt = make_tracer(name, W, H, max_leaf_tris=leaf)
+    assert_hits_equal(pt.trace_primary(), ref)
+
+
+def test_soup_scene_from_global_memory(require_gpu):
+    """200k-triangle soup (too large for LDS): closest hits and occlusion against the exhaustive oracle on a sample
+    of camera rays and random interior rays."""
+    fl = soup(200000, seed=0x5EED)
+    W, H = 96, 54
+    pt = P.PathTracer(W, H)
+    pt.upload_scene(fl['v'], fl['n'], fl['mat_idx'], fl['materials'])
+    cam = P.Camera(30.0, H / W).setTransform((250, 180, 160), (0, 0, 0), (0, 0, 1))
+    pt.set_camera(cam)
+    assert pt.stats().sceneInLds == 0
+    o = oracle_py.Oracle(fl, build_tree=False); o.configure(width=W, height=H); o.set_camera(cam.state)
+    assert_hits_equal(pt.trace_primary(), o.trace_primary(0, W * H, use_tree=False))
+    rays = random_rays(fl, 3000, 5)
+    tri, t, u, v, _ = pt.trace(rays)
+    assert_hits_equal((tri, t, u, v), o.trace_rays(rays, kind=0))
+    assert np.array_equal(pt.hitsNothing(rays), o.trace_rays(rays, kind=1)[0] < 0)
+
+
+def test_degenerate_inputs(require_gpu):
+    mats = np.array([[0, .7, .7, .7]], np.float32)
+    pt = P.PathTracer(32, 32)
+    pt.set_camera(P.Camera(30.0, 1.0).setTransform((0, -5, 0), (0, 0, 0), (0, 0, 1)))
+    pt.upload_scene(np.zeros((0, 9), np.float32), np.zeros((0, 9), np.float32), np.zeros(0, np.uint32), mats)   # empty scene
+    tri, t, _, _ = pt.trace_primary()
+    assert (tri == -1).all() and (t > 3e38).all()
+    assert pt.hitsNothing(np.array([[0, -5, 0, 0, 1, 0]], np.float32)).all()
+    # one front-facing triangle, one zero-area triangle, one triangle with a NaN vertex, one back-facing triangle
+    v = np.array([[-1, 0, -1, 0, 0, 1, 1, 0, -1],            # normal +y?  (v1-v0)x(v2-v0) = (1,0,2)x(2,0,0) = (0,4,0)... faces +y
+                  [0, 1, 0, 0, 1, 0, 0, 1, 0],
+                  [np.nan, 2, 0, 1, 2, 0, 0, 2, 1],
+                  [-1, 3, -1, 1, 3, -1, 0, 3, 1]], np.float32)
+    pt.upload_scene(v, v, np.zeros(4, np.uint32), mats)
+    o = oracle_py.Oracle({'v': v, 'n': v, 'mat_idx': np.zeros(4, np.uint32), 'materials': mats}, build_tree=False)
+    rays = np.array([[0, -5, 0, 0, 1, 0], [0, 10, 0, 0, -1, 0], [0, -5, 0, 0, -1, 0], [0, -5, 0, np.nan, 1, 0],
+                     [0, 0, 0, 0, 1, 0], [0.2, -5, 0.1, 0, 1, 0]], np.float32)
+    tri, t, u, v2, _ = pt.trace(rays)
+    assert_hits_equal((tri, t, u, v2), o.trace_rays(rays, kind=0))
+    assert np.array_equal(pt.hitsNothing(rays), o.trace_rays(rays, kind=1)[0] < 0)
+    assert set(tri.tolist()) <= {-1, 0, 3}
+
+
+def test_visit_counters_match_cpu_restatement_of_the_traversal(require_gpu, flats):
+    """PT_FLAG_COUNT_VISITS (the per-ray node / triangle figures of the roofline) against the oracle walking the
+    same flattened BVH in the same order.  The kernels use the hardware reciprocal in the slab test, the oracle
+    1/x, so a box can flip at the margin: agreement to 0.1 %."""
+    name, W, H = 'teapot', 320, 180
+    pt = make_tracer(name, W, H, flags=P.PT_FLAG_COUNT_VISITS)
+    o = make_oracle(flats[name], name, W, H)
+    nodes, order = pt.get_bvh()
+    root = int(nodes[0, 3:4].view(np.uint32)[0])
+    pt.reset_stats(); pt.trace_primary()
+    st = pt.stats()
+    n_nodes, n_tris, _ = o.bvh_count(nodes, root, order, o.view_rays(0, W * H))
+    assert abs(st.nodesClosest - n_nodes) <= 1e-3 * n_nodes
+    assert abs(st.trisClosest - n_tris) <= 1e-3 * n_tris

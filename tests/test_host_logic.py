@@ -1,0 +1,171 @@
+"""Host-side pieces of the product (no GPU): light table, camera state, flattened BVH, band partition."""
+import numpy as np
+import pytest
+
+import oracle_py
+import pathtracer_amd as P
+from pathtracer_amd import multigpu
+from conftest import CAMERAS, UP, make_oracle, model_path, soup
+
+NAMES = sorted(CAMERAS)
+COUNT_SHIFT, INDEX_MASK = 28, (1 << 28) - 1
+
+
+def host_tracer(name=None, flat=None, **cfg):
+    pt = P.PathTracer(64, 64, device=-1, **cfg)
+    if name:
+        pt.Scene(model_path(name))
+    else:
+        pt.upload_scene(flat['v'], flat['n'], flat['mat_idx'], flat['materials'])
+    return pt
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_light_table_equals_oracle(name, flats):
+    got = host_tracer(name).light_groups()
+    ref = oracle_py.Oracle(flats[name], build_tree=False).light_groups()
+    assert len(got) == len(ref)
+    for (gr, ga), (rr, ra) in zip(got, ref):
+        assert np.array_equal(gr.view(np.uint32), rr.view(np.uint32)) and ga == ra
+
+
+def test_light_groups_one_per_emissive_material_in_triangle_order():
+    """rendering.d:116-161: groups follow material order, members follow triangle order."""
+    fl = soup(40, seed=1)
+    fl['materials'] = np.array([[0, .7, .7, .7], [2.0, 1, 0, 0], [0, .1, .1, .1], [3.0, 0, 1, 0]], np.float32)
+    fl['mat_idx'] = (np.arange(len(fl['v'])) % 4).astype(np.uint32)
+    got = host_tracer(flat=fl).light_groups()
+    ref = oracle_py.Oracle(fl, build_tree=False).light_groups()
+    assert len(got) == 2
+    for (gr, ga), (rr, ra) in zip(got, ref):
+        assert np.array_equal(gr, rr) and ga == ra
+        assert abs(gr[:, 10].sum() - 1) < 1e-5
+    first_light_tri = fl['v'][1]
+    assert np.array_equal(got[0][0][0, :3], first_light_tri[0])
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_camera_state_equals_oracle(name):
+    for aspect in (1.0, 0.5625, 0.75):
+        c = P.Camera(30.0, aspect).setTransform(CAMERAS[name][0], CAMERAS[name][1], UP).state
+        r = oracle_py.camera_lookat(30.0, aspect, CAMERAS[name][0], CAMERAS[name][1], UP)
+        assert np.array_equal(c.view(np.uint32), r.view(np.uint32))
+
+
+def walk_bvh(nodes, order, root_ref):
+    """Returns (leaf slots visited, max depth); asserts the structural invariants on the way."""
+    seen = np.zeros(len(order), int)
+    max_depth = 0
+    stack = [(root_ref, None, 0)]
+    while stack:
+        ref, box, depth = stack.pop()
+        max_depth = max(max_depth, depth)
+        cnt, idx = ref >> COUNT_SHIFT, ref & INDEX_MASK
+        if cnt:
+            seen[idx:idx + cnt] += 1
+            continue
+        for k in (0, 1):
+            n = nodes[2 * idx + k]
+            cref = int(n[3:4].view(np.uint32)[0])
+            cb = (n[0:3], n[4:7])
+            if box is not None:                                  # child box inside parent box
+                assert (cb[0] >= box[0] - 1e-6).all() and (cb[1] <= box[1] + 1e-6).all()
+            stack.append((cref, cb, depth + 1))
+    return seen, max_depth
+
+
+def leaf_boxes(nodes, root_ref):
+    out = []
+    stack = [(root_ref, None)]
+    while stack:
+        ref, box = stack.pop()
+        cnt, idx = ref >> COUNT_SHIFT, ref & INDEX_MASK
+        if cnt:
+            out.append((idx, cnt, box))
+            continue
+        for k in (0, 1):
+            n = nodes[2 * idx + k]
+            stack.append((int(n[3:4].view(np.uint32)[0]), (n[0:3], n[4:7])))
+    return out
+
+
+@pytest.mark.parametrize('name,leaf', [(n, l) for n in NAMES for l in (1, 4, 15)])
+def test_bvh_structure(name, leaf, flats):
+    pt = host_tracer(name, max_leaf_tris=leaf)
+    nodes, order = pt.get_bvh()
+    st = pt.stats()
+    root_ref = int(nodes[0, 3:4].view(np.uint32)[0])
+    v = flats[name]['v']
+    degenerate = (v[:, 0] == v[:, 1]).all(1) | (v[:, 0] == v[:, 2]).all(1)
+    n_leaf_tris = int((~degenerate).sum())
+    order = order[:n_leaf_tris]
+    seen, depth = walk_bvh(nodes, order, root_ref)
+    assert (seen == 1).all()                                     # every leaf slot reachable exactly once
+    assert sorted(order.tolist()) == np.flatnonzero(~degenerate).tolist()   # every non-degenerate triangle exactly once
+    assert depth == st.bvhDepth and depth <= 60
+    for idx, cnt, box in leaf_boxes(nodes, root_ref):
+        assert 1 <= cnt <= leaf
+        if box is not None:
+            tv = v[order[idx:idx + cnt]].reshape(-1, 3)
+            assert (tv >= box[0]).all() and (tv <= box[1]).all()  # padded box contains its triangles
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_bvh_traversal_finds_the_exhaustive_hit(name, flats):
+    """The kernels' traversal order restated on the CPU, over the product's own flattened BVH, must accept the
+    same triangle as the exhaustive search (closest hit) and agree on occlusion (any hit)."""
+    W = H = 96
+    pt = host_tracer(name)
+    nodes, order = pt.get_bvh()
+    root_ref = int(nodes[0, 3:4].view(np.uint32)[0])
+    o = make_oracle(flats[name], name, W, H)
+    rays = o.view_rays(0, W * H)
+    n_nodes, n_tris, tri = o.bvh_count(nodes, root_ref, order, rays, any_hit=False)
+    ref_tri = o.trace_primary(0, W * H, use_tree=False)[0]
+    assert np.array_equal(tri, ref_tri)
+    assert n_nodes >= 2 * W * H and n_tris < o.T * W * H / 4      # far fewer triangle tests than exhaustive
+    rng = np.random.default_rng(7)
+    lo, hi = flats[name]['v'].reshape(-1, 3).min(0), flats[name]['v'].reshape(-1, 3).max(0)
+    org = rng.uniform(lo - 2, hi + 2, (4000, 3)); d = rng.normal(size=(4000, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rr = np.concatenate([org, d], 1).astype(np.float32)
+    _, _, tri_c = o.bvh_count(nodes, root_ref, order, rr, any_hit=False)
+    assert np.array_equal(tri_c, o.trace_rays(rr, kind=0)[0])
+    _, _, tri_a = o.bvh_count(nodes, root_ref, order, rr, any_hit=True)
+    assert np.array_equal(tri_a >= 0, o.trace_rays(rr, kind=1)[0] >= 0)
+
+
+def test_bvh_on_soup_and_degenerate_inputs():
+    fl = soup(20000, seed=3)
+    fl['v'][5] = fl['v'][5][[0, 0, 2]]                           # v0 == v1: can never be hit, left out of the tree
+    fl['v'][6, 1, 0] = np.nan
+    pt = host_tracer(flat=fl)
+    nodes, order = pt.get_bvh()
+    st = pt.stats()
+    assert st.numTriangles == 20002
+    order = order[:20000]
+    assert 5 not in order and 6 not in order
+    seen, depth = walk_bvh(nodes, order, int(nodes[0, 3:4].view(np.uint32)[0]))
+    assert (seen == 1).all() and depth < 40
+
+
+def test_empty_and_single_triangle_scenes():
+    mats = np.array([[0, .7, .7, .7]], np.float32)
+    pt = P.PathTracer(8, 8, device=-1)
+    pt.upload_scene(np.zeros((0, 9), np.float32), np.zeros((0, 9), np.float32), np.zeros(0, np.uint32), mats)
+    assert pt.stats().numTriangles == 0 and pt.stats().numLightGroups == 0
+    one = np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], np.float32)
+    pt.upload_scene(one, one, np.zeros(1, np.uint32), mats)
+    nodes, order = pt.get_bvh()
+    assert int(nodes[0, 3:4].view(np.uint32)[0]) >> COUNT_SHIFT == 1 and order[0] == 0
+
+
+@pytest.mark.parametrize('height,band_rows,world', [(1080, 4, 8), (240, 4, 3), (37, 4, 2), (5, 4, 8), (2160, 16, 4)])
+def test_band_partition_covers_every_row_once(height, band_rows, world):
+    """main.d:184-192's bands dealt round-robin to ranks: a partition of the rows."""
+    rows = [multigpu.rows_of_rank(height, band_rows, r, world) for r in range(world)]
+    flat = sorted(x for r in rows for x in r)
+    assert flat == list(range(height))
+    sizes = [len(r) for r in rows]
+    assert max(sizes) - min(sizes) <= band_rows
+    with pytest.raises(ValueError):
+        multigpu.band_share(world, world)
