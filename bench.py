@@ -94,7 +94,8 @@ def main():
     pt.reset_stats()
     pt.render_frame(1); pt.synchronize()
     cst = pt.stats()
-    n_closest = max(1, cst.raysPrimary + cst.raysLight + cst.raysIndirect)
+    # view rays that miss the scene's bounding box are answered in raygen (one box test, no traversal kernel)
+    n_closest = max(1, cst.raysPrimary - cst.raysCulled + cst.raysLight + cst.raysIndirect)
     n_any = max(1, cst.raysOcclusion)
     visits = dict(nodes_closest=cst.nodesClosest / n_closest, tris_closest=cst.trisClosest / n_closest,
                   nodes_any=cst.nodesAny / n_any, tris_any=cst.trisAny / n_any)
@@ -136,7 +137,7 @@ def main():
         closest_rays = st.raysPrimary + st.raysLight + st.raysIndirect
         if closest_ms >= any_ms:
             dom, dom_ms, dom_launch, dom_bytes = 'extend (closest hit)', st.kernelMs[0], st.kernelLaunches[0], \
-                (st.raysPrimary + st.raysIndirect) * bytes_closest
+                (st.raysPrimary - st.raysCulled + st.raysIndirect) * bytes_closest
         else:
             dom, dom_ms, dom_launch, dom_bytes = 'occluded (any hit)', any_ms, st.kernelLaunches[2], st.raysOcclusion * bytes_any
         achieved = dom_bytes / max(1, dom_launch) / (dom_ms / max(1, dom_launch) * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -165,8 +166,8 @@ def main():
                        'bvh_nodes': int(st.numNodes)},
             'spp_per_s': round(samples / (W * H) / elapsed, 2), 'Msamples_per_s': round(samples / elapsed / 1e6, 2),
             'rays_per_sample': round(rays / max(1.0, samples), 4),
-            'rays': {'primary': int(st.raysPrimary), 'light': int(st.raysLight), 'indirect': int(st.raysIndirect),
-                     'occlusion': int(st.raysOcclusion)},
+            'rays': {'primary': int(st.raysPrimary), 'primary_culled_by_scene_box': int(st.raysCulled),
+                     'light': int(st.raysLight), 'indirect': int(st.raysIndirect), 'occlusion': int(st.raysOcclusion)},
             'device_ms_per_step_rank0': round(st.renderMs / args.steps, 3), 'readback_ms': round(readback_ms, 3),
             'kernels': kern, 'roofline': roofline, 'cpu_baseline': cpu,
         }

@@ -75,6 +75,7 @@ typedef struct PtStats {
   uint64_t samples;          /* computeL invocations                                                     */
   uint64_t nodesClosest, trisClosest;   /* with PT_FLAG_COUNT_VISITS: box tests / triangle tests, closest-hit rays */
   uint64_t nodesAny, trisAny;           /* same for any-hit rays                                          */
+  uint64_t raysCulled;       /* view rays answered by the scene bounding box alone (included in raysPrimary) */
   double kernelMs[PT_K_COUNT];          /* with PT_FLAG_TIME_KERNELS: summed event time per kernel kind   */
   uint64_t kernelLaunches[PT_K_COUNT];
   double renderMs;           /* event time first kernel -> last kernel of all ptgpu_render calls          */

@@ -58,6 +58,7 @@ struct PtHandle {
   DevBuf accOwn; float4* acc = nullptr; uint64_t accBytes = 0;
   // wavefront buffers
   DevBuf bHit, bRayO[2], bRayD[2], bLacc, bThr, bRng, bShO, bShD, bShW, bCounters, bStats;
+  DevBuf bMetaDesc; std::vector<QMeta> metas;     // queue descriptors: device copy and host copy, stage-major
   Wavefront wf{}; uint32_t wfKinds = 0, wfRounds = 0;
   // statistics
   PtStats st{};
@@ -99,11 +100,12 @@ DevCfg makeDevCfg(const PtHandle* h) {
   d.skyRadiance = v3(c.skyRadiance[0], c.skyRadiance[1], c.skyRadiance[2]);
   d.eps = c.floatEpsilon; d.rrProb = c.rrProb; d.maxDepth = c.maxDepth; d.numIndirect = c.numIndirect;
   d.seed = c.seed; d.sampleBase = c.sampleBase; d.cam = h->cam;
+  d.divW = makeFastDiv(c.width);
   return d;
 }
 
 LaunchCfg makeLaunchCfg(const PtHandle* h) {
-  return LaunchCfg{h->numCUs, (h->cfg.flags & PT_FLAG_COUNT_VISITS) != 0, h->stream};
+  return LaunchCfg{h->cfg.device, h->numCUs, (h->cfg.flags & PT_FLAG_COUNT_VISITS) != 0, h->stream};
 }
 
 hipEvent_t getEvent(PtHandle* h) {
@@ -120,7 +122,11 @@ struct Timed {
     if (on) { a = getEvent(h); b = getEvent(h); HIPCHECK(hipEventRecord(a, h->stream)); }
     if (kind < PT_K_COUNT) h->st.kernelLaunches[kind]++;
   }
-  void done() { if (on) { HIPCHECK(hipEventRecord(b, h->stream)); h->pending.push_back(EventPair{a, b, kind}); on = false; } }
+  void done() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) fail(PT_E_DEVICE, "kernel launch failed (kind " + std::to_string(kind) + "): " + hipGetErrorString(e));
+    if (on) { HIPCHECK(hipEventRecord(b, h->stream)); h->pending.push_back(EventPair{a, b, kind}); on = false; }
+  }
 };
 
 void resolveEvents(PtHandle* h) {
@@ -199,6 +205,7 @@ void uploadScene(PtHandle* h) {
   d.lightArea = h->dLightArea.as<float>();
   d.numNodes = bvh.numNodes; d.numTris = NT; d.numOrigTris = T; d.rootRef = bvh.rootRef;
   d.numLightGroups = (uint32_t)lt.numGroups();
+  d.boxMin = v3(bvh.nodes[0], bvh.nodes[1], bvh.nodes[2]); d.boxMax = v3(bvh.nodes[4], bvh.nodes[5], bvh.nodes[6]);
   size_t ldsNeed = ((size_t)2 * bvh.numNodes + (size_t)3 * NT) * 16;
   d.ldsBytes = (!(h->cfg.flags & PT_FLAG_NO_LDS_SCENE) && ldsNeed <= 156 * 1024) ? (uint32_t)ldsNeed : 0;
   h->haveScene = true;
@@ -210,27 +217,45 @@ uint32_t numKinds(const PtHandle* h) { return h->dsc.numLightGroups + 2; }
 
 void ensureWavefront(PtHandle* h) {
   const PtConfig& c = h->cfg;
-  uint32_t capSlots = c.batchSlots ? c.batchSlots : (c.mode == 1 ? (1u << 20) : (1u << 22));
+  // Large batches keep every launch far above the 2048 threads x 256 CUs that are resident at once (a 4 M-slot
+  // batch leaves ~1.4 shadow rays per resident thread and the tail dominates); HBM has room: ~210 B per slot.
+  uint64_t want = c.batchSlots ? c.batchSlots : (c.mode == 1 ? (1u << 22) : (1u << 24));
   uint64_t frame = (uint64_t)c.width * c.height;
-  // no point in more slots than 64 samples of the whole frame
-  capSlots = (uint32_t)std::max<uint64_t>(1024, std::min<uint64_t>(capSlots, frame * 64));
+  // no point in more slots than 64 samples of the whole frame; a multiple of 64 * PT_SEGS so that every block-task's
+  // share of a full batch is whole waves and fits its output segment
+  const uint64_t gran = 64ull * PT_SEGS;
+  want = std::min<uint64_t>(want, frame * 64);
+  uint32_t capSlots = (uint32_t)std::min<uint64_t>(((want + gran - 1) / gran) * gran, 0x40000000ull);
   uint32_t NI = c.mode == 1 ? c.numIndirect : 0;
   uint32_t lanes = 1 + NI;
   uint64_t capQueue = (uint64_t)capSlots * std::max(1u, NI);
   if (capQueue > 0x7FFFFFFFull) fail(PT_E_INVALID, "batchSlots * numIndirect too large");
-  uint32_t kinds = numKinds(h), rounds = c.mode == 1 ? c.maxDepth + 3 : 1;
+  uint32_t kinds = numKinds(h), rounds = c.mode == 1 ? c.maxDepth + 4 : 2;
   Wavefront& w = h->wf;
   if (w.capSlots == capSlots && w.capQueue == (uint32_t)capQueue && w.lanes == lanes && h->wfKinds == kinds && h->wfRounds == rounds) return;
   HIPCHECK(hipStreamSynchronize(h->stream));
   h->bHit.alloc(capQueue * 16);
-  for (int q = 0; q < 2; q++) { h->bRayO[q].alloc(NI ? capQueue * 16 : 16); h->bRayD[q].alloc(NI ? capQueue * 16 : 16); }
+  // queue 0 always carries the view rays that entered the scene's box; queue 1 only exists with indirect rays
+  for (int q = 0; q < 2; q++) { h->bRayO[q].alloc(NI || q == 0 ? capQueue * 16 : 16); h->bRayD[q].alloc(NI || q == 0 ? capQueue * 16 : 16); }
   h->bLacc.alloc((uint64_t)lanes * capSlots * 16);
   h->bThr.alloc(NI ? (uint64_t)lanes * capSlots * 16 : 16);
   h->bRng.alloc(NI ? (uint64_t)lanes * capSlots * 8 : 16);
   h->bShO.alloc((uint64_t)kinds * capQueue * 16);
   h->bShD.alloc((uint64_t)kinds * capQueue * 16);
   h->bShW.alloc((uint64_t)kinds * capQueue * 16);
-  h->bCounters.alloc((size_t)rounds * PT_COUNTER_SET * 4);
+  // queue bookkeeping: stage s owns 1 + PT_MAX_KINDS queues (ray queue it fills, its shadow queues)
+  const uint32_t perStage = 1 + PT_MAX_KINDS;
+  h->bCounters.alloc((size_t)rounds * perStage * PT_QMETA_WORDS * 4 + PT_TASK_COUNTERS * 4);
+  h->bMetaDesc.alloc((size_t)rounds * perStage * sizeof(QMeta));
+  h->metas.resize((size_t)rounds * perStage);
+  uint32_t* words = h->bCounters.as<uint32_t>();
+  for (size_t m = 0; m < h->metas.size(); m++) {
+    uint32_t* p = words + m * PT_QMETA_WORDS;
+    h->metas[m] = QMeta{p, p + PT_SEGS, p + 2 * PT_SEGS + 2};
+  }
+  HIPCHECK(hipMemset(h->bCounters.p, 0, h->bCounters.bytes));
+  HIPCHECK(hipMemcpy(h->bMetaDesc.p, h->metas.data(), h->metas.size() * sizeof(QMeta), hipMemcpyHostToDevice));
+  w.taskCounters = words + h->metas.size() * PT_QMETA_WORDS;
   w.hit = h->bHit.as<float4>();
   for (int q = 0; q < 2; q++) { w.rayO[q] = h->bRayO[q].as<float4>(); w.rayD[q] = h->bRayD[q].as<float4>(); }
   w.Lacc = h->bLacc.as<float4>(); w.thr = h->bThr.as<float4>(); w.rng = h->bRng.as<uint2>();
@@ -251,30 +276,59 @@ void launchShadowKinds(PtHandle* h, const LaunchCfg& lc, const DevCfg& dc, const
     for (int s = 0; s < 2; s++, kind++) { Timed t(h, PT_K_OCCLUDED); launchOccluded(lc, h->dsc, dc, wf, kind); t.done(); }
 }
 
-// One wavefront batch: npix pixels x k samples.
+// One wavefront batch: npix pixels x k samples.  Counter set s belongs to stage s: 0 = raygen, 1 = shading of the
+// view-ray hits, 2 + r = shading of the indirect hits of round r; a stage reads the ray queue its predecessor filled.
 void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm) {
   Wavefront wf = h->wf;
-  uint32_t* counters = h->bCounters.as<uint32_t>();
+  const uint32_t perStage = 1 + PT_MAX_KINDS;
+  const int kinds = (int)((dc.hasLights ? h->dsc.numLightGroups : 0) + (dc.hasSky ? 2 : 0));
+  const QMeta* desc = h->bMetaDesc.as<QMeta>();
+  // stage s: 0 = raygen, 1 = shading of the view-ray hits, 2 + r = shading of the indirect hits of round r.
+  // A stage fills its own ray queue and shadow queues; the scan after it makes them readable.
+  auto bind = [&](uint32_t stage) {
+    wf.rayIn = h->metas[(size_t)(stage - 1) * perStage];
+    wf.rayOut = h->metas[(size_t)stage * perStage];
+    for (int k = 0; k < PT_MAX_KINDS; k++) wf.sh[k] = h->metas[(size_t)stage * perStage + 1 + k];
+  };
+  auto scan = [&](uint32_t stage, int n) {
+    Timed t(h, PT_K_OTHER); launchScan(lc, desc + (size_t)stage * perStage, n, wf.taskCounters); t.done();
+  };
   uint32_t nslots = pm.npix * pm.k;
-  HIPCHECK(hipMemsetAsync(counters, 0, (size_t)h->wfRounds * PT_COUNTER_SET * 4, h->stream));
-  wf.cntIn = counters; wf.cntOut = counters;          // round 0 writes set 0
-  { Timed t(h, PT_K_EXTEND); launchExtendPrimary(lc, h->dsc, dc, pm, h->acc, nslots, 1, wf.hit, wf.stats); t.done(); }
-  { Timed t(h, PT_K_SHADE); launchShade(lc, h->dsc, dc, pm, h->acc, wf, true, nslots, 0, 0); t.done(); }
+  wf.rayOut = h->metas[0];
+  { Timed t(h, PT_K_OTHER); launchRaygen(lc, h->dsc, dc, pm, h->acc, nslots, wf, 0); t.done(); }
+  scan(0, 1);
+  bind(1);
+  { Timed t(h, PT_K_EXTEND); launchExtendQueue(lc, h->dsc, dc, wf, 0, -1); t.done(); }
+  { Timed t(h, PT_K_SHADE); launchShade(lc, h->dsc, dc, pm, h->acc, wf, true, 0, 1); t.done(); }
+  scan(1, 1 + kinds);
   launchShadowKinds(h, lc, dc, wf);
   h->st.raysPrimary += nslots; h->st.samples += nslots;
   if (dc.mode == 1) {
     // depth 0..maxDepth can still spawn a ray (the check is depth > maxDepth, rendering.d:380)
     for (uint32_t round = 0; round <= dc.maxDepth; round++) {
-      int qIn = round & 1, qOut = qIn ^ 1;
-      wf.cntIn = counters + (size_t)round * PT_COUNTER_SET;
-      wf.cntOut = counters + (size_t)(round + 1) * PT_COUNTER_SET;
+      int qIn = (round + 1) & 1, qOut = qIn ^ 1;
+      bind(round + 2);
       { Timed t(h, PT_K_EXTEND); launchExtendQueue(lc, h->dsc, dc, wf, qIn, STAT_RAYS_INDIRECT); t.done(); }
-      { Timed t(h, PT_K_SHADE); launchShade(lc, h->dsc, dc, pm, h->acc, wf, false, 0, qIn, qOut); t.done(); }
+      { Timed t(h, PT_K_SHADE); launchShade(lc, h->dsc, dc, pm, h->acc, wf, false, qIn, qOut); t.done(); }
+      scan(round + 2, 1 + kinds);
       launchShadowKinds(h, lc, dc, wf);
     }
   }
   { Timed t(h, PT_K_ACCUM); launchAccumulate(lc, dc, pm, h->acc, wf); t.done(); }
   HIPCHECK(hipGetLastError());
+}
+
+// Slots are laid out so that a wave's 64 paths are a compact block of pixels (8x8, or 16x4 when only multiples of
+// 4 rows are available) whenever the chunk is made of whole rows; otherwise in scanline order.
+void chooseTiling(PixMap& pm, uint32_t W, bool wholeRows) {
+  pm.tileW = 0; pm.tilesPerRow = 1;
+  if (wholeRows && pm.npix % W == 0 && pm.lpBase % W == 0) {
+    uint32_t rows = pm.npix / W;
+    if (rows % 8 == 0 && W % 8 == 0) pm.tileW = 8;
+    else if (rows % 4 == 0 && W % 16 == 0) pm.tileW = 16;
+    if (pm.tileW) pm.tilesPerRow = W / pm.tileW;
+  }
+  pm.divTilesPerRow = makeFastDiv(pm.tilesPerRow);
 }
 
 void renderPixels(PtHandle* h, PixMap base, uint64_t totalPix, uint32_t spp) {
@@ -284,12 +338,19 @@ void renderPixels(PtHandle* h, PixMap base, uint64_t totalPix, uint32_t spp) {
   ensureWavefront(h);
   DevCfg dc = makeDevCfg(h); LaunchCfg lc = makeLaunchCfg(h);
   Timed span(h, KIND_RENDER, true);
-  uint32_t cap = h->wf.capSlots;
-  for (uint64_t lp0 = 0; lp0 < totalPix; lp0 += cap) {
-    uint32_t npix = (uint32_t)std::min<uint64_t>(cap, totalPix - lp0);
-    uint32_t kmax = std::max(1u, cap / npix);
+  uint32_t W = h->cfg.width;
+  bool wholeRows = (base.bandPix != 0 || base.offset % W == 0) && totalPix % W == 0;
+  uint64_t cap = h->wf.capSlots;
+  uint64_t chunk = std::min<uint64_t>(cap, totalPix);
+  if (wholeRows && chunk < totalPix && chunk >= 8ull * W) chunk -= chunk % (8ull * W);     // chunks of whole 8-row strips
+  base.divBand = makeFastDiv(base.bandPix);
+  for (uint64_t lp0 = 0; lp0 < totalPix; lp0 += chunk) {
+    uint32_t npix = (uint32_t)std::min<uint64_t>(chunk, totalPix - lp0);
+    uint32_t kmax = std::max<uint32_t>(1u, (uint32_t)(cap / npix));
     for (uint32_t s0 = 0; s0 < spp; s0 += kmax) {
       PixMap pm = base; pm.lpBase = (uint32_t)lp0; pm.npix = npix; pm.k = std::min(kmax, spp - s0);
+      pm.divNpix = makeFastDiv(npix);
+      chooseTiling(pm, W, wholeRows);
       renderBatch(h, dc, lc, pm);
     }
   }
@@ -575,6 +636,7 @@ int ptgpu_trace_primary(PtHandle* h, uint32_t off, uint32_t count, int32_t* triI
     if (!count) return;
     DevBuf dh; dh.alloc((size_t)count * 16);
     PixMap pm{}; pm.offset = off; pm.npix = count; pm.k = 1;
+    pm.divNpix = makeFastDiv(count); pm.divBand = makeFastDiv(0); pm.tilesPerRow = 1; pm.divTilesPerRow = makeFastDiv(1);
     launchExtendPrimary(makeLaunchCfg(h), h->dsc, makeDevCfg(h), pm, h->acc, count, 0, dh.as<float4>(), h->bStats.as<unsigned long long>());
     HIPCHECK(hipGetLastError());
     std::vector<float> tmp((size_t)count * 4);
@@ -626,7 +688,7 @@ int ptgpu_get_stats(PtHandle* h, PtStats* out) {
     HIPCHECK(hipMemcpy(s, h->bStats.p, sizeof(s), hipMemcpyDeviceToHost));
     h->st.raysLight = s[STAT_RAYS_LIGHT]; h->st.raysIndirect = s[STAT_RAYS_INDIRECT]; h->st.raysOcclusion = s[STAT_RAYS_OCCL];
     h->st.nodesClosest = s[STAT_NODES_CLOSEST]; h->st.trisClosest = s[STAT_TRIS_CLOSEST];
-    h->st.nodesAny = s[STAT_NODES_ANY]; h->st.trisAny = s[STAT_TRIS_ANY];
+    h->st.nodesAny = s[STAT_NODES_ANY]; h->st.trisAny = s[STAT_TRIS_ANY]; h->st.raysCulled = s[STAT_RAYS_CULLED];
     *out = h->st;
   });
 }

@@ -5,6 +5,25 @@
 
 namespace pt {
 
+// Division by a run-time constant without the ~30-instruction software divide (Granlund-Montgomery):
+// q = (t + ((n - t) >> s1)) >> s2 with t = umulhi(m, n); exact for every 32-bit n.
+struct FastDiv { uint32_t m, s1, s2, d; };
+inline FastDiv makeFastDiv(uint32_t d) {
+  FastDiv f; f.d = d ? d : 1;
+  uint32_t l = 0; while ((1ull << l) < f.d) l++;
+  f.m = (uint32_t)(((1ull << 32) * ((1ull << l) - f.d)) / f.d + 1);
+  f.s1 = l < 1 ? l : 1; f.s2 = l > 1 ? l - 1 : 0;
+  return f;
+}
+PT_HD uint32_t fdiv(const FastDiv& f, uint32_t n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t t = __umulhi(f.m, n);
+#else
+  uint32_t t = (uint32_t)(((uint64_t)f.m * n) >> 32);
+#endif
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
 // Everything the traversal and shading kernels read.  All arrays live in HBM; when ldsBytes != 0 the
 // traversal kernels copy nodes + tris into LDS once per workgroup and traverse from there.
 struct DevScene {
@@ -18,6 +37,7 @@ struct DevScene {
   const float* lightArea;     // g_totalLightSourceArea
   uint32_t numNodes, numTris, numOrigTris, rootRef, numLightGroups;
   uint32_t ldsBytes;          // 0 => traverse from global memory
+  V3 boxMin, boxMax;          // padded bounds of the whole scene (the root node's box)
 };
 
 struct DevCfg {               // PtConfig + camera as the kernels need them
@@ -26,19 +46,55 @@ struct DevCfg {               // PtConfig + camera as the kernels need them
   float eps, rrProb;
   uint32_t maxDepth, numIndirect, seed, sampleBase;
   Camera cam;
+  FastDiv divW;
 };
 
-// Which pixels a batch covers.  Local pixel lp (0..npix) of the batch is pixel
-//   offset + lpBase + lp                                   (bandPix == 0: contiguous window)
-//   (bandFirst + j*bandStride)*bandPix + r,  j = q / bandPix, r = q % bandPix, q = lpBase + lp   (band set)
-// and path slot = sample * npix + lp.
-struct PixMap { uint32_t offset, bandPix, bandFirst, bandStride, lpBase, npix, k; };
+// Which pixels a batch covers and in which order.  Path slot i = sample * npix + lp.  Local pixel lp is first
+// mapped to a position q in the batch's pixel list -- linearly (tileW == 0), or so that each run of 64 slots is a
+// tileW x (64/tileW) block of pixels (coherent rays per wave; needs whole rows) -- and q to a frame pixel:
+//   offset + lpBase + q                                    (bandPix == 0: contiguous window)
+//   (bandFirst + j*bandStride)*bandPix + r, j = (lpBase+q) / bandPix, r = (lpBase+q) % bandPix   (band set)
+struct PixMap {
+  uint32_t offset, bandPix, bandFirst, bandStride, lpBase, npix, k;
+  uint32_t tileW, tilesPerRow;      // tile shape and tiles per row of the frame
+  FastDiv divNpix, divBand, divTilesPerRow;
+};
 
-constexpr int PT_MAX_KINDS = 10;   // shadow-ray kinds per vertex: light groups + sun + sky
-constexpr int PT_COUNTER_SET = 16;  // words per counter set (1 + PT_MAX_KINDS, padded)
+PT_HD uint32_t mapPixel(const PixMap& pm, uint32_t W, uint32_t lp) {
+  uint32_t q = lp;
+  if (pm.tileW) {
+    uint32_t tile = lp >> 6, in = lp & 63u;
+    uint32_t tr = fdiv(pm.divTilesPerRow, tile), tc = tile - tr * pm.tilesPerRow;
+    uint32_t tx, ty;
+    if (pm.tileW == 8) { tx = in & 7u; ty = in >> 3; } else { tx = in & 15u; ty = in >> 4; }
+    uint32_t th = 64u / pm.tileW;
+    q = (tr * th + ty) * W + tc * pm.tileW + tx;
+  }
+  q += pm.lpBase;
+  if (pm.bandPix == 0) return pm.offset + q;
+  uint32_t j = fdiv(pm.divBand, q), r = q - j * pm.bandPix;
+  return (pm.bandFirst + j * pm.bandStride) * pm.bandPix + r;
+}
+
+constexpr int PT_MAX_KINDS = 10;    // shadow-ray kinds per vertex: light groups + sun + sky
+
+// Queues are SEGMENTED: every stage splits its input into PT_SEGS block-tasks of P consecutive entries, and
+// block-task T appends what it emits to segment T of each output queue (entries T*segCap .. T*segCap+count[T]).
+// No global atomic and no device-wide ordering is involved in an append: lanes rank themselves with a wave64
+// ballot + mbcnt and waves of the workgroup share an LDS counter.  A one-workgroup scan per queue then turns the
+// PT_SEGS counts into prefix sums, so that the next stage sees a dense queue: flat entry j lives in the segment s
+// with prefix[s] <= j < prefix[s+1], at s*segCap + (j - prefix[s]).
+constexpr uint32_t PT_SEGS = 1024;
+struct QMeta {
+  uint32_t* count;            // [PT_SEGS]      entries per segment, written by the producing stage
+  uint32_t* prefix;           // [PT_SEGS + 2]  exclusive prefix sums; [PT_SEGS] = total, [PT_SEGS + 1] = P of the consumers
+  uint32_t* start;            // [PT_SEGS]      segment that holds flat entry T*P: where consumer block-task T starts
+};
+constexpr uint32_t PT_QMETA_WORDS = 3 * PT_SEGS + 2;
+constexpr int PT_TASK_COUNTERS = 16;   // one dynamic block-task counter per traversal launch of a stage
 
 struct Wavefront {
-  float4* hit;                // per ray-queue entry: (t, u, v, triId)
+  float4* hit;                // per flat ray-queue entry: (t, u, v, triId)
   float4* rayO[2];            // ray queues (ping-pong): (origin.xyz, lane slot)
   float4* rayD[2];            //                          (dir.xyz, 0)
   float4* Lacc;               // per lane slot: radiance gathered by this lane (xyz), primary-hit flag (w)
@@ -47,30 +103,36 @@ struct Wavefront {
   float4* shO;                // shadow queues, kind-major: (origin.xyz, lane slot)
   float4* shD;                //                            (dir.xyz, light distance)
   float4* shW;                //                            (weight.xyz, n.omega)
-  uint32_t* cntIn;            // counter set written by the previous round: [0] = ray queue length
-  uint32_t* cntOut;           // counter set of this round: [0] ray queue being filled, [1 + kind] shadow queues
+  QMeta rayIn;                // ray queue this stage reads
+  QMeta rayOut;               // ray queue this stage fills
+  QMeta sh[PT_MAX_KINDS];     // shadow queues of this stage
+  uint32_t* taskCounters;     // [PT_TASK_COUNTERS], zeroed by the scan that precedes the launches using them
   unsigned long long* stats;  // see STAT_*
-  uint32_t capSlots;          // primary slots per batch
+  uint32_t capSlots;          // primary slots per batch (multiple of 64 * PT_SEGS)
   uint32_t capQueue;          // entries per queue (capSlots * max(1, numIndirect) in mode 1)
   uint32_t lanes;             // 1 + numIndirect in mode 1, else 1
 };
 
 enum { STAT_RAYS_LIGHT = 0, STAT_RAYS_INDIRECT, STAT_RAYS_OCCL, STAT_NODES_CLOSEST, STAT_TRIS_CLOSEST,
-       STAT_NODES_ANY, STAT_TRIS_ANY, STAT_COUNT };
+       STAT_NODES_ANY, STAT_TRIS_ANY, STAT_RAYS_CULLED, STAT_COUNT };
 
-struct LaunchCfg { int numCUs; bool countVisits; hipStream_t stream; };
+struct LaunchCfg { int device; int numCUs; bool countVisits; hipStream_t stream; };
 
 // ---- wavefront stages (all asynchronous on lc.stream) ----
-void launchExtendPrimary(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
-                         uint32_t nslots, int jitter, float4* hit, unsigned long long* stats);
+void launchRaygen(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
+                  uint32_t nslots, const Wavefront& wf, int qOut);
+// prefix sums + consumer start segments for n queues, and zeroing of the stage's dynamic task counters
+void launchScan(const LaunchCfg& lc, const QMeta* metas, int n, uint32_t* taskCounters);
 void launchExtendQueue(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int q, int statSlot);
 void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
-                 const Wavefront& wf, bool primary, uint32_t nslots, int qIn, int qOut);
+                 const Wavefront& wf, bool primary, int qIn, int qOut);
 void launchConnect(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, float area);
 void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind);
 void launchAccumulate(const LaunchCfg& lc, const DevCfg& cfg, const PixMap& pm, float4* acc, const Wavefront& wf);
 
 // ---- stand-alone operators ----
+void launchExtendPrimary(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
+                         uint32_t nslots, int jitter, float4* hit, unsigned long long* stats);
 void launchViewRays(const LaunchCfg& lc, const DevCfg& cfg, uint32_t pixelOffset, uint32_t count, float* rays6);
 void launchTraceRays(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const float* rays6, uint32_t count,
                      int32_t* triId, float* t, float* u, float* v, float* normal3);

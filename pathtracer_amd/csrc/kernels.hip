@@ -3,17 +3,21 @@
 // One sample of the reference's computeL (rendering.d:464-484) is split into stages that each run over a
 // whole batch of paths; the stages talk through structure-of-arrays queues in HBM:
 //
-//   extend (primary)   getViewRay + Scene.trace            rendering.d:467-471, scene.d:681-743
+//   raygen             getViewRay (rendering.d:278-285) + the part of Scene.trace that can be decided against the
+//                      scene's bounding box: rays that miss it take the `else` branch of computeL right away
+//                      (sampleSky, rendering.d:480); the rest are compacted into a ray queue
+//   extend             Scene.trace (scene.d:681-743) of a ray queue: view rays, later the indirect rays
 //   shade              computeL / computeLdirect / computeLindirect bodies between the trace calls
 //                                                           rendering.d:376-462, 472-481
 //   connect            Scene.trace of a light-sample ray + the G term   rendering.d:414-425
 //   occluded           Scene.hitsNothing of the sun / sky rays          rendering.d:440-443, 455-457
-//   extend (queue)     Scene.trace of the indirect rays                 rendering.d:389
 //   accumulate         sum += L; n += 1                                  rendering.d:477-483
 //
-// Live paths are compacted when they are appended to the next queue: a wave64 ballot + mbcnt gives each
-// lane its rank, wave totals are combined through LDS and ONE atomic per workgroup reserves the range
-// (a single 4-byte word sustains < 10^8 atomics/s, far less than one per wave at these ray rates).
+// Live paths are compacted when they are appended to the next queue.  Queues are segmented (kernels.h, QMeta):
+// a lane's rank inside its wave comes from a wave64 ballot + mbcnt, the wave's base from an LDS counter of its
+// workgroup, the workgroup's base is the fixed start of its segment -- no global atomic is on the data path (a
+// single 4-byte word sustains < 10^8 atomics/s, which at these ray rates is less than one per workgroup).
+// k_scan turns the per-segment counts into the prefix sums the next stage indexes with.
 //
 // Traversal: stack-based, near child first, over the BVH2 of bvh.h.  When the scene fits, nodes and
 // triangles are staged in LDS once per (persistent) workgroup; otherwise they are read from HBM/L2.
@@ -23,6 +27,9 @@
 #include "kernels.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <mutex>
+#include <set>
+#include <utility>
 
 namespace pt {
 
@@ -34,13 +41,6 @@ __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
 __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ V3 xyz(float4 a) { return v3(a.x, a.y, a.z); }
 __device__ __forceinline__ float4 f4(V3 a, float w) { return make_float4(a.x, a.y, a.z, w); }
-
-__device__ __forceinline__ uint32_t mapPixel(const PixMap& pm, uint32_t lp) {
-  uint32_t q = pm.lpBase + lp;
-  if (pm.bandPix == 0) return pm.offset + q;
-  uint32_t j = q / pm.bandPix, r = q - j * pm.bandPix;
-  return (pm.bandFirst + j * pm.bandStride) * pm.bandPix + r;
-}
 
 template <bool LDSS> __device__ __forceinline__ float4 ldNode(const DevScene& sc, uint32_t i) {
   if constexpr (LDSS) return g_lds[i]; else return sc.nodes[i];
@@ -58,18 +58,35 @@ template <bool LDSS> __device__ __forceinline__ void stageScene(const DevScene& 
   }
 }
 
+// Reciprocal direction for the slab test.  Only the (conservative) box test uses it, never the triangle test.
+struct RayInv { float ix, iy, iz, ox, oy, oz; };
+__device__ __forceinline__ RayInv makeRayInv(V3 o, V3 d) {
+  float dx = fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x;
+  float dy = fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y;
+  float dz = fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z;
+  RayInv r;
+  r.ix = __builtin_amdgcn_rcpf(dx); r.iy = __builtin_amdgcn_rcpf(dy); r.iz = __builtin_amdgcn_rcpf(dz);
+  r.ox = -o.x * r.ix; r.oy = -o.y * r.iy; r.oz = -o.z * r.iz;
+  return r;
+}
+// Entry distance of the ray into the box [mn, mx]; hit iff tn <= min(far * (1 + 2 ulp), tmax).
+__device__ __forceinline__ bool slab(const RayInv& r, float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                                     float tmax, float& tn) {
+  float p0x = fmaf(mnx, r.ix, r.ox), p1x = fmaf(mxx, r.ix, r.ox);
+  float p0y = fmaf(mny, r.iy, r.oy), p1y = fmaf(mxy, r.iy, r.oy);
+  float p0z = fmaf(mnz, r.iz, r.oz), p1z = fmaf(mxz, r.iz, r.oz);
+  tn = fmaxf(fmaxf(fminf(p0x, p1x), fminf(p0y, p1y)), fmaxf(fminf(p0z, p1z), 0.0f));
+  float tf = fminf(fminf(fmaxf(p0x, p1x), fmaxf(p0y, p1y)), fmaxf(p0z, p1z)) * 1.0000005f;
+  return tn <= fminf(tf, tmax);
+}
+
 struct Hit { float t, u, v; uint32_t tri; };
 
 // Closest front-face hit (ANY = false: Scene.trace, scene.d:691-740) or first hit of either face
 // (ANY = true: Scene.hitsNothing, scene.d:808-835).  Returns true if something was accepted.
 template <bool ANY, bool LDSS, bool COUNT>
 __device__ __forceinline__ bool traverse(const DevScene& sc, V3 o, V3 d, float eps, Hit& h, uint32_t& cN, uint32_t& cT) {
-  float dx = fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x;
-  float dy = fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y;
-  float dz = fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z;
-  float ix = __builtin_amdgcn_rcpf(dx), iy = __builtin_amdgcn_rcpf(dy), iz = __builtin_amdgcn_rcpf(dz);
-  float ox = -o.x * ix, oy = -o.y * iy, oz = -o.z * iz;
-
+  RayInv ri = makeRayInv(o, d);
   h.t = PT_FLT_MAX; h.u = 0.0f; h.v = 0.0f; h.tri = 0xFFFFFFFFu;
   bool found = false;
   uint32_t stack[64];
@@ -82,17 +99,9 @@ __device__ __forceinline__ bool traverse(const DevScene& sc, V3 o, V3 d, float e
       float4 a0 = ldNode<LDSS>(sc, b), a1 = ldNode<LDSS>(sc, b + 1);
       float4 b0 = ldNode<LDSS>(sc, b + 2), b1 = ldNode<LDSS>(sc, b + 3);
       if (COUNT) cN += 2;
-      float p0x = fmaf(a0.x, ix, ox), p1x = fmaf(a1.x, ix, ox);
-      float p0y = fmaf(a0.y, iy, oy), p1y = fmaf(a1.y, iy, oy);
-      float p0z = fmaf(a0.z, iz, oz), p1z = fmaf(a1.z, iz, oz);
-      float tn0 = fmaxf(fmaxf(fminf(p0x, p1x), fminf(p0y, p1y)), fmaxf(fminf(p0z, p1z), 0.0f));
-      float tf0 = fminf(fminf(fmaxf(p0x, p1x), fmaxf(p0y, p1y)), fmaxf(p0z, p1z)) * 1.0000005f;
-      float q0x = fmaf(b0.x, ix, ox), q1x = fmaf(b1.x, ix, ox);
-      float q0y = fmaf(b0.y, iy, oy), q1y = fmaf(b1.y, iy, oy);
-      float q0z = fmaf(b0.z, iz, oz), q1z = fmaf(b1.z, iz, oz);
-      float tn1 = fmaxf(fmaxf(fminf(q0x, q1x), fminf(q0y, q1y)), fmaxf(fminf(q0z, q1z), 0.0f));
-      float tf1 = fminf(fminf(fmaxf(q0x, q1x), fmaxf(q0y, q1y)), fmaxf(q0z, q1z)) * 1.0000005f;
-      bool h0 = tn0 <= fminf(tf0, h.t), h1 = tn1 <= fminf(tf1, h.t);
+      float tn0, tn1;
+      bool h0 = slab(ri, a0.x, a0.y, a0.z, a1.x, a1.y, a1.z, h.t, tn0);
+      bool h1 = slab(ri, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, h.t, tn1);
       uint32_t r0 = f2u(a0.w), r1 = f2u(b0.w);
       if (h0 && h1) {
         bool sw = tn1 < tn0;
@@ -149,26 +158,151 @@ template <bool COUNT> __device__ __forceinline__ void flushCounts(unsigned long 
   }
 }
 
-// Workgroup-aggregated queue append.  Every thread of the workgroup must call it the same number of times.
-// sm: 2 * 20 words of LDS scratch, `phase` alternates 0/1 between consecutive calls.
-__device__ __forceinline__ uint32_t blockAppend(bool pred, uint32_t* counter, uint32_t* sm, int& phase) {
-  uint32_t* s = sm + phase * 20; phase ^= 1;
+// ------------------------------------------------------------------------------------------------ segmented queues
+// Append from converged code (every lane of the wave executes the call): rank by ballot + mbcnt, one LDS atomic per wave.
+__device__ __forceinline__ uint32_t waveAppend(bool pred, uint32_t* ldsCounter) {
   unsigned long long mask = __ballot(pred);
   uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-  uint32_t wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-  if ((threadIdx.x & 63) == 0) s[wave] = (uint32_t)__popcll(mask);
+  uint32_t base = 0;
+  if ((threadIdx.x & 63) == 0 && mask) base = atomicAdd(ldsCounter, (uint32_t)__popcll(mask));
+  base = __builtin_amdgcn_readfirstlane(base);
+  return base + rank;
+}
+
+// Flat input range of block-task T and the segment it starts in.
+struct Task { uint32_t begin, end, seg; };
+__device__ __forceinline__ Task taskOf(const QMeta& q, uint32_t T) {
+  uint32_t total = q.prefix[PT_SEGS], P = q.prefix[PT_SEGS + 1];
+  Task t; t.begin = T * P; t.end = min(t.begin + P, total); t.seg = q.start[T];
+  return t;
+}
+// Physical index of flat entry j; seg is the lane's cursor (j only grows within a block-task).
+__device__ __forceinline__ uint32_t physIndex(const QMeta& q, uint32_t j, uint32_t& seg, uint32_t segCap) {
+  uint32_t lo = q.prefix[seg], hi = q.prefix[seg + 1];
+  while (j >= hi) { seg++; lo = hi; hi = q.prefix[seg + 1]; }
+  return seg * segCap + (j - lo);
+}
+__device__ __forceinline__ uint32_t dense64(uint32_t total) { return ((total + PT_SEGS - 1) / PT_SEGS + 63u) & ~63u; }
+
+// One workgroup per queue: exclusive prefix of the PT_SEGS counts, total, consumers' P and start segments.
+__global__ void __launch_bounds__(1024) k_scan(const QMeta* __restrict__ metas, uint32_t* taskCounters) {
+  __shared__ uint32_t sp[PT_SEGS + 1];
+  __shared__ uint32_t wsum[16];
+  QMeta q = metas[blockIdx.x];
+  uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (blockIdx.x == 0 && tid < PT_TASK_COUNTERS) taskCounters[tid] = 0;
+  uint32_t c = q.count[tid], x = c;
+  for (int off = 1; off < 64; off <<= 1) { uint32_t y = __shfl_up(x, off); if (lane >= (uint32_t)off) x += y; }   // inclusive in wave
+  if (lane == 63) wsum[wave] = x;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t total = 0;
-    for (uint32_t w = 0; w < nw; w++) { uint32_t c = s[w]; s[w] = total; total += c; }
-    s[18] = total ? atomicAdd(counter, total) : 0u;
+  uint32_t base = 0;
+  for (uint32_t w = 0; w < wave; w++) base += wsum[w];
+  uint32_t excl = base + x - c;
+  sp[tid] = excl;
+  if (tid == PT_SEGS - 1) sp[PT_SEGS] = excl + c;
+  __syncthreads();
+  uint32_t total = sp[PT_SEGS], P = dense64(total);
+  q.prefix[tid] = excl;
+  if (tid == 0) { q.prefix[PT_SEGS] = total; q.prefix[PT_SEGS + 1] = P; }
+  // segment s with sp[s] <= target < sp[s+1] (skipping empty segments); past the end: last segment
+  uint32_t target = tid * P, s = PT_SEGS - 1;
+  if (target < total) {
+    uint32_t lo = 0, hi = PT_SEGS;                       // invariant: sp[lo] <= target < sp[hi]
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (sp[mid] <= target) lo = mid; else hi = mid; }
+    s = lo;
   }
+  q.start[tid] = s;
+}
+
+// Dynamic block-task distribution for the persistent traversal kernels (PT_SEGS atomics per launch).
+__device__ __forceinline__ bool nextTask(uint32_t* counter, uint32_t* sTask, uint32_t& T) {
   __syncthreads();
-  return s[18] + s[wave] + rank;
+  if (threadIdx.x == 0) *sTask = atomicAdd(counter, 1u);
+  __syncthreads();
+  T = *sTask;
+  return T < PT_SEGS;
+}
+
+// (pixel, sample index, view ray) of path slot i: getViewRay, rendering.d:278-285
+struct PrimaryRay { uint32_t gp, sampleIdx; V3 d; Rng g; };
+__device__ __forceinline__ PrimaryRay primaryRay(const DevCfg& cfg, const PixMap& pm, const float4* __restrict__ acc, uint32_t i,
+                                                 bool jitter) {
+  PrimaryRay r;
+  uint32_t s = fdiv(pm.divNpix, i), lp = i - s * pm.npix;
+  r.gp = mapPixel(pm, cfg.W, lp);
+  uint32_t row = fdiv(cfg.divW, r.gp), col = r.gp - row * cfg.W;
+  float x, y;
+  if (jitter) {
+    r.sampleIdx = cfg.sampleBase + (uint32_t)acc[r.gp].w + s;
+    r.g.seed(cfg.seed, r.gp, r.sampleIdx, 0);
+    viewRayXY(col, row, cfg.W, cfg.H, &r.g, x, y);
+  } else {
+    r.sampleIdx = 0; r.g.s0 = 1; r.g.s1 = 0;
+    viewRayXY(col, row, cfg.W, cfg.H, nullptr, x, y);
+  }
+  r.d = screenRayDir(cfg.cam, x, y);
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------ raygen
+// Block-task T = blockIdx.x covers slots [T*P, (T+1)*P); the rays that enter the scene's box go to segment T.
+__global__ void __launch_bounds__(256) k_raygen(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, uint32_t nslots,
+                                                Wavefront wf, int qOut) {
+  __shared__ uint32_t sCnt;
+  if (threadIdx.x == 0) sCnt = 0;
+  __syncthreads();
+  uint32_t T = blockIdx.x, P = dense64(nslots), begin = T * P, end = min(begin + P, nslots);
+  uint32_t segCap = wf.capQueue / PT_SEGS, culled = 0;
+  for (uint32_t base = begin; base < end; base += blockDim.x) {
+    uint32_t i = base + threadIdx.x;
+    bool enter = false;
+    V3 d = v3(0, 0, 0);
+    if (i < end) {
+      PrimaryRay pr = primaryRay(cfg, pm, acc, i, true);
+      d = pr.d;
+      RayInv ri = makeRayInv(cfg.cam.pos, d);
+      float tn;
+      enter = slab(ri, sc.boxMin.x, sc.boxMin.y, sc.boxMin.z, sc.boxMax.x, sc.boxMax.y, sc.boxMax.z, PT_FLT_MAX, tn);
+      if (!enter) { wf.Lacc[i] = f4(sampleSky(d), 0.0f); culled++; }         // rendering.d:480
+    }
+    uint32_t idx = waveAppend(enter, &sCnt);
+    if (enter) {
+      uint32_t e = T * segCap + idx;
+      wf.rayO[qOut][e] = f4(cfg.cam.pos, u2f(i));
+      wf.rayD[qOut][e] = f4(d, 0.0f);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) culled += __shfl_down(culled, off);
+  if ((threadIdx.x & 63) == 0 && culled) atomicAdd(&wf.stats[STAT_RAYS_CULLED], (unsigned long long)culled);
+  __syncthreads();
+  if (threadIdx.x == 0) wf.rayOut.count[T] = sCnt;
 }
 
 // ------------------------------------------------------------------------------------------------ extend
-// Primary rays: the view ray is generated in registers (no ray queue) and the hit record is the only HBM write.
+// Closest hit for every entry of a ray queue; hit[] is indexed by the flat entry number.
+template <bool LDSS, bool COUNT>
+__global__ void __launch_bounds__(1024) k_extend_queue(DevScene sc, float eps, QMeta q, uint32_t segCap, const float4* __restrict__ rayO,
+                                                       const float4* __restrict__ rayD, uint32_t* taskCounter,
+                                                       float4* __restrict__ hit, unsigned long long* stats, int statSlot) {
+  __shared__ __align__(16) uint32_t sTask[4];
+  stageScene<LDSS>(sc);
+  uint32_t cN = 0, cT = 0, T;
+  if (statSlot >= 0 && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[statSlot], (unsigned long long)q.prefix[PT_SEGS]);
+  while (nextTask(taskCounter, sTask, T)) {
+    Task tk = taskOf(q, T);
+    uint32_t seg = tk.seg;
+    for (uint32_t j = tk.begin + threadIdx.x; j < tk.end; j += blockDim.x) {
+      uint32_t e = physIndex(q, j, seg, segCap);
+      float4 ro = rayO[e], rd = rayD[e];
+      Hit h;
+      traverse<false, LDSS, COUNT>(sc, xyz(ro), xyz(rd), eps, h, cN, cT);
+      hit[j] = make_float4(h.t, h.u, h.v, u2f(h.tri));
+    }
+  }
+  flushCounts<COUNT>(stats, STAT_NODES_CLOSEST, cN, cT);
+}
+
+// View rays generated in registers, no cull, no queue: the parity probe (getViewRay without jitter + Scene.trace).
 template <bool LDSS, bool COUNT>
 __global__ void __launch_bounds__(1024) k_extend_primary(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc,
                                                          uint32_t nslots, int jitter, float4* __restrict__ hit,
@@ -176,33 +310,9 @@ __global__ void __launch_bounds__(1024) k_extend_primary(DevScene sc, DevCfg cfg
   stageScene<LDSS>(sc);
   uint32_t cN = 0, cT = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += gridDim.x * blockDim.x) {
-    uint32_t s = i / pm.npix, lp = i - s * pm.npix;
-    uint32_t gp = mapPixel(pm, lp);
-    float x, y;
-    if (jitter) {
-      Rng g; g.seed(cfg.seed, gp, cfg.sampleBase + (uint32_t)acc[gp].w + s, 0);
-      viewRayXY(gp, cfg.W, cfg.H, &g, x, y);
-    } else viewRayXY(gp, cfg.W, cfg.H, nullptr, x, y);
-    V3 d = screenRayDir(cfg.cam, x, y);
+    PrimaryRay pr = primaryRay(cfg, pm, acc, i, jitter != 0);
     Hit h;
-    traverse<false, LDSS, COUNT>(sc, cfg.cam.pos, d, cfg.eps, h, cN, cT);
-    hit[i] = make_float4(h.t, h.u, h.v, u2f(h.tri));
-  }
-  flushCounts<COUNT>(stats, STAT_NODES_CLOSEST, cN, cT);
-}
-
-// Queued rays (indirect bounces): closest hit for every entry of ray queue q.
-template <bool LDSS, bool COUNT>
-__global__ void __launch_bounds__(1024) k_extend_queue(DevScene sc, float eps, const float4* __restrict__ rayO,
-                                                       const float4* __restrict__ rayD, const uint32_t* __restrict__ count,
-                                                       float4* __restrict__ hit, unsigned long long* stats, int statSlot) {
-  stageScene<LDSS>(sc);
-  uint32_t n = *count, cN = 0, cT = 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[statSlot], (unsigned long long)n);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float4 ro = rayO[i], rd = rayD[i];
-    Hit h;
-    traverse<false, LDSS, COUNT>(sc, xyz(ro), xyz(rd), eps, h, cN, cT);
+    traverse<false, LDSS, COUNT>(sc, cfg.cam.pos, pr.d, cfg.eps, h, cN, cT);
     hit[i] = make_float4(h.t, h.u, h.v, u2f(h.tri));
   }
   flushCounts<COUNT>(stats, STAT_NODES_CLOSEST, cN, cT);
@@ -213,32 +323,38 @@ __global__ void __launch_bounds__(1024) k_extend_queue(DevScene sc, float eps, c
 // At most one entry per lane slot and launch, so the read-modify-write of Lacc needs no atomics and the
 // per-lane order of additions (light 0, light 1, ..., sun, sky) is the launch order.
 template <bool LDSS, bool COUNT>
-__global__ void __launch_bounds__(1024) k_connect(DevScene sc, float eps, const float4* __restrict__ shO,
+__global__ void __launch_bounds__(1024) k_connect(DevScene sc, float eps, QMeta q, uint32_t segCap, const float4* __restrict__ shO,
                                                   const float4* __restrict__ shD, const float4* __restrict__ shW,
-                                                  const uint32_t* __restrict__ count, float area, float4* __restrict__ Lacc,
+                                                  uint32_t* taskCounter, float area, float4* __restrict__ Lacc,
                                                   unsigned long long* stats) {
+  __shared__ __align__(16) uint32_t sTask[4];
   stageScene<LDSS>(sc);
-  uint32_t n = *count, cN = 0, cT = 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[STAT_RAYS_LIGHT], (unsigned long long)n);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float4 ro = shO[i], rd = shD[i];
-    V3 phi = xyz(rd);
-    Hit h;
-    if (traverse<false, LDSS, COUNT>(sc, xyz(ro), phi, eps, h, cN, cT)) {
-      float lightDistance = rd.w;
-      if (h.t > lightDistance - eps) {
-        float4 w = shW[i];
-        float4 q0 = sc.nrm[3 * h.tri], q1 = sc.nrm[3 * h.tri + 1], q2 = sc.nrm[3 * h.tri + 2];
-        V3 normalY = interpNormal(xyz(q0), xyz(q1), xyz(q2), h.u, h.v);
-        float4 m = sc.mats[f2u(q0.w)];
-        V3 Le = m.x * v3(m.y, m.z, m.w);
-        float G = w.w * dot(normalY, -phi) / (lightDistance * lightDistance);
-        if (!(G > 0.0f)) G = 0.0f;
-        V3 c = xyz(w) * Le * G * area;
-        uint32_t slot = f2u(ro.w);
-        float4 L = Lacc[slot];
-        L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z;
-        Lacc[slot] = L;
+  uint32_t cN = 0, cT = 0, T;
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[STAT_RAYS_LIGHT], (unsigned long long)q.prefix[PT_SEGS]);
+  while (nextTask(taskCounter, sTask, T)) {
+    Task tk = taskOf(q, T);
+    uint32_t seg = tk.seg;
+    for (uint32_t j = tk.begin + threadIdx.x; j < tk.end; j += blockDim.x) {
+      uint32_t e = physIndex(q, j, seg, segCap);
+      float4 ro = shO[e], rd = shD[e];
+      V3 phi = xyz(rd);
+      Hit h;
+      if (traverse<false, LDSS, COUNT>(sc, xyz(ro), phi, eps, h, cN, cT)) {
+        float lightDistance = rd.w;
+        if (h.t > lightDistance - eps) {
+          float4 w = shW[e];
+          float4 q0 = sc.nrm[3 * h.tri], q1 = sc.nrm[3 * h.tri + 1], q2 = sc.nrm[3 * h.tri + 2];
+          V3 normalY = interpNormal(xyz(q0), xyz(q1), xyz(q2), h.u, h.v);
+          float4 m = sc.mats[f2u(q0.w)];
+          V3 Le = m.x * v3(m.y, m.z, m.w);
+          float G = w.w * dot(normalY, -phi) / (lightDistance * lightDistance);
+          if (!(G > 0.0f)) G = 0.0f;
+          V3 c = xyz(w) * Le * G * area;
+          uint32_t slot = f2u(ro.w);
+          float4 L = Lacc[slot];
+          L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z;
+          Lacc[slot] = L;
+        }
       }
     }
   }
@@ -247,22 +363,27 @@ __global__ void __launch_bounds__(1024) k_connect(DevScene sc, float eps, const 
 
 // Sun / sky rays: Scene.hitsNothing + `L += ...`, rendering.d:440-443 and 455-457.
 template <bool LDSS, bool COUNT>
-__global__ void __launch_bounds__(1024) k_occluded(DevScene sc, float eps, const float4* __restrict__ shO,
+__global__ void __launch_bounds__(1024) k_occluded(DevScene sc, float eps, QMeta q, uint32_t segCap, const float4* __restrict__ shO,
                                                    const float4* __restrict__ shD, const float4* __restrict__ shW,
-                                                   const uint32_t* __restrict__ count, float4* __restrict__ Lacc,
-                                                   unsigned long long* stats) {
+                                                   uint32_t* taskCounter, float4* __restrict__ Lacc, unsigned long long* stats) {
+  __shared__ __align__(16) uint32_t sTask[4];
   stageScene<LDSS>(sc);
-  uint32_t n = *count, cN = 0, cT = 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[STAT_RAYS_OCCL], (unsigned long long)n);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float4 ro = shO[i], rd = shD[i];
-    Hit h;
-    if (!traverse<true, LDSS, COUNT>(sc, xyz(ro), xyz(rd), eps, h, cN, cT)) {
-      float4 w = shW[i];
-      uint32_t slot = f2u(ro.w);
-      float4 L = Lacc[slot];
-      L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z;
-      Lacc[slot] = L;
+  uint32_t cN = 0, cT = 0, T;
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[STAT_RAYS_OCCL], (unsigned long long)q.prefix[PT_SEGS]);
+  while (nextTask(taskCounter, sTask, T)) {
+    Task tk = taskOf(q, T);
+    uint32_t seg = tk.seg;
+    for (uint32_t j = tk.begin + threadIdx.x; j < tk.end; j += blockDim.x) {
+      uint32_t e = physIndex(q, j, seg, segCap);
+      float4 ro = shO[e], rd = shD[e];
+      Hit h;
+      if (!traverse<true, LDSS, COUNT>(sc, xyz(ro), xyz(rd), eps, h, cN, cT)) {
+        float4 w = shW[e];
+        uint32_t slot = f2u(ro.w);
+        float4 L = Lacc[slot];
+        L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z;
+        Lacc[slot] = L;
+      }
     }
   }
   flushCounts<COUNT>(stats, STAT_NODES_ANY, cN, cT);
@@ -270,7 +391,7 @@ __global__ void __launch_bounds__(1024) k_occluded(DevScene sc, float eps, const
 
 // ------------------------------------------------------------------------------------------------ shade
 struct ShadeCtx {
-  const DevScene& sc; const DevCfg& cfg; const Wavefront& wf; uint32_t* sm; int phase;
+  const DevScene& sc; const DevCfg& cfg; const Wavefront& wf; uint32_t* sCnt; uint32_t T, segCapRay, segCapSh;
 };
 
 // One computeLindirect head (rendering.d:378-385): Russian roulette, direction, ray; appended to ray queue qOut.
@@ -286,19 +407,30 @@ __device__ __forceinline__ void bounce(ShadeCtx& cx, bool active, Rng& g, uint32
       alive = true;
     }
   }
-  uint32_t idx = blockAppend(alive, &cx.wf.cntOut[0], cx.sm, cx.phase);
+  uint32_t idx = waveAppend(alive, &cx.sCnt[0]);
   if (alive) {
-    cx.wf.rayO[qOut][idx] = f4(pos + normal * 0.1f, u2f(laneSlot));
-    cx.wf.rayD[qOut][idx] = f4(dir, 0.0f);
+    uint32_t e = cx.T * cx.segCapRay + idx;
+    cx.wf.rayO[qOut][e] = f4(pos + normal * 0.1f, u2f(laneSlot));
+    cx.wf.rayD[qOut][e] = f4(dir, 0.0f);
     // BRDF * PI * color == color: the factor the caller multiplies computeLrefl with (rendering.d:391)
     cx.wf.thr[laneSlot] = f4(T * color, u2f(depth + 1));
     cx.wf.rng[laneSlot] = make_uint2(g.s0, g.s1);
   }
 }
 
+__device__ __forceinline__ void emitShadow(ShadeCtx& cx, int kind, bool emit, V3 org, V3 dir, float dw, V3 w, float ww, uint32_t laneSlot) {
+  uint32_t idx = waveAppend(emit, &cx.sCnt[1 + kind]);
+  if (emit) {
+    size_t e = (size_t)kind * cx.wf.capQueue + cx.T * cx.segCapSh + idx;
+    cx.wf.shO[e] = f4(org, u2f(laneSlot));
+    cx.wf.shD[e] = f4(dir, dw);
+    cx.wf.shW[e] = f4(w, ww);
+  }
+}
+
 // computeLdirect up to (not including) the trace calls, rendering.d:396-462: emits one shadow ray per kind.
 __device__ __forceinline__ void directLight(ShadeCtx& cx, bool active, Rng& g, V3 x, V3 normalX, V3 Tw, uint32_t laneSlot) {
-  const DevScene& sc = cx.sc; const DevCfg& cfg = cx.cfg; const Wavefront& wf = cx.wf;
+  const DevScene& sc = cx.sc; const DevCfg& cfg = cx.cfg;
   float eps = cfg.eps;
   int kind = 0;
   if (cfg.hasLights) {
@@ -323,13 +455,7 @@ __device__ __forceinline__ void directLight(ShadeCtx& cx, bool active, Rng& g, V
         ndot = dot(normalX, phi);
         emit = ndot > eps;
       }
-      uint32_t idx = blockAppend(emit, &wf.cntOut[1 + kind], cx.sm, cx.phase);
-      if (emit) {
-        size_t e = (size_t)kind * wf.capQueue + idx;
-        wf.shO[e] = f4(x + normalX * eps, u2f(laneSlot));
-        wf.shD[e] = f4(phi, lightDistance);
-        wf.shW[e] = f4(Tw, ndot);
-      }
+      emitShadow(cx, kind, emit, x + normalX * eps, phi, lightDistance, Tw, ndot, laneSlot);
     }
   }
   if (cfg.hasSky) {
@@ -342,13 +468,7 @@ __device__ __forceinline__ void directLight(ShadeCtx& cx, bool active, Rng& g, V
         emit = dot(normalX, dir) > eps;
         c = Tw * cfg.sunRadiance * dot(normalX, cfg.sunDir);
       }
-      uint32_t idx = blockAppend(emit, &wf.cntOut[1 + kind], cx.sm, cx.phase);
-      if (emit) {
-        size_t e = (size_t)kind * wf.capQueue + idx;
-        wf.shO[e] = f4(x + normalX * 0.1f, u2f(laneSlot));
-        wf.shD[e] = f4(dir, 0.0f);
-        wf.shW[e] = f4(c, 0.0f);
-      }
+      emitShadow(cx, kind, emit, x + normalX * 0.1f, dir, 0.0f, c, 0.0f, laneSlot);
       kind++;
     }
     {  // sky, rendering.d:448-459
@@ -361,50 +481,50 @@ __device__ __forceinline__ void directLight(ShadeCtx& cx, bool active, Rng& g, V
         emit = nd > eps;
         c = Tw * cfg.skyRadiance * nd;
       }
-      uint32_t idx = blockAppend(emit, &wf.cntOut[1 + kind], cx.sm, cx.phase);
-      if (emit) {
-        size_t e = (size_t)kind * wf.capQueue + idx;
-        wf.shO[e] = f4(x + normalX * 0.1f, u2f(laneSlot));
-        wf.shD[e] = f4(dir, 0.0f);
-        wf.shW[e] = f4(c, 0.0f);
-      }
+      emitShadow(cx, kind, emit, x + normalX * 0.1f, dir, 0.0f, c, 0.0f, laneSlot);
       kind++;
     }
   }
 }
 
-// PRIMARY: the part of computeL after the view-ray trace (rendering.d:471-481).  Entry i is path slot i; the
-// view ray is regenerated from (pixel, sample) instead of being read back.
+// PRIMARY: the part of computeL after the view-ray trace (rendering.d:471-481) for the view rays that entered the
+// scene's box; the generator of (pixel, sample) is re-seeded and stepped past the two jitter draws.
 // !PRIMARY: the part of computeLindirect after its trace (rendering.d:389-392) = computeLrefl at the hit.
+// Block-task T = blockIdx.x reads flat entries [T*P, (T+1)*P) of the input ray queue and fills segment T of the
+// output queues.
 template <bool PRIMARY>
-__global__ void __launch_bounds__(512) k_shade(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, Wavefront wf,
-                                               uint32_t nIn, int qIn, int qOut) {
-  __shared__ uint32_t sm[40];
-  ShadeCtx cx{sc, cfg, wf, sm, 0};
-  uint32_t n = PRIMARY ? nIn : wf.cntIn[0];
-  for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
-    uint32_t i = base + threadIdx.x;
-    bool valid = i < n, isHit = false;
-    V3 o = v3(0, 0, 0), d = v3(0, 0, 0), T = v3(1, 1, 1);
+__global__ void __launch_bounds__(256) k_shade(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, Wavefront wf,
+                                               int qIn, int qOut, int numKinds) {
+  __shared__ uint32_t sCnt[1 + PT_MAX_KINDS];
+  if (threadIdx.x <= PT_MAX_KINDS) sCnt[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t T = blockIdx.x;
+  uint32_t segCapIn = wf.capQueue / PT_SEGS;
+  ShadeCtx cx{sc, cfg, wf, sCnt, T, wf.capQueue / PT_SEGS, wf.capQueue / PT_SEGS};
+  Task tk = taskOf(wf.rayIn, T);
+  uint32_t seg = tk.seg;
+  for (uint32_t base = tk.begin; base < tk.end; base += blockDim.x) {
+    uint32_t j = base + threadIdx.x;
+    bool valid = j < tk.end, isHit = false;
+    V3 o = v3(0, 0, 0), d = v3(0, 0, 0), Tp = v3(1, 1, 1);
     uint32_t laneSlot = 0, depth = 0, gp = 0, sampleIdx = 0;
     Rng g; g.s0 = 1; g.s1 = 0;
     float4 hr = make_float4(0, 0, 0, 0);
     if (valid) {
-      hr = wf.hit[i];
+      uint32_t e = physIndex(wf.rayIn, j, seg, segCapIn);
+      hr = wf.hit[j];
       isHit = f2u(hr.w) != 0xFFFFFFFFu;
-      if (PRIMARY) {
-        uint32_t s = i / pm.npix, lp = i - s * pm.npix;
-        gp = mapPixel(pm, lp);
-        sampleIdx = cfg.sampleBase + (uint32_t)acc[gp].w + s;
-        g.seed(cfg.seed, gp, sampleIdx, 0);
-        float x, y; viewRayXY(gp, cfg.W, cfg.H, &g, x, y);
-        o = cfg.cam.pos; d = screenRayDir(cfg.cam, x, y);
-        laneSlot = i;
-      } else {
-        float4 ro = wf.rayO[qIn][i], rd = wf.rayD[qIn][i];
-        o = xyz(ro); d = xyz(rd); laneSlot = f2u(ro.w);
-        if (isHit) {
-          float4 t4 = wf.thr[laneSlot]; T = xyz(t4); depth = f2u(t4.w);
+      float4 ro = wf.rayO[qIn][e], rd = wf.rayD[qIn][e];
+      o = xyz(ro); d = xyz(rd); laneSlot = f2u(ro.w);
+      if (isHit) {
+        if (PRIMARY) {
+          uint32_t s = fdiv(pm.divNpix, laneSlot), lp = laneSlot - s * pm.npix;
+          gp = mapPixel(pm, cfg.W, lp);
+          sampleIdx = cfg.sampleBase + (uint32_t)acc[gp].w + s;
+          g.seed(cfg.seed, gp, sampleIdx, 0);
+          g.next(); g.next();                                          // the x and y jitter of getViewRay
+        } else {
+          float4 t4 = wf.thr[laneSlot]; Tp = xyz(t4); depth = f2u(t4.w);
           uint2 r = wf.rng[laneSlot]; g.s0 = r.x; g.s1 = r.y;
         }
       }
@@ -425,21 +545,24 @@ __global__ void __launch_bounds__(512) k_shade(DevScene sc, DevCfg cfg, PixMap p
     } else if (valid && PRIMARY) {
       wf.Lacc[laneSlot] = f4(sampleSky(d), 0.0f);                      // rendering.d:480
     }
-    V3 Tw = T * (PT_BRDF * color);
+    V3 Tw = Tp * (PT_BRDF * color);
     directLight(cx, active, g, hitPos, normal, Tw, laneSlot);
     if (cfg.mode == 1) {
       if (PRIMARY) {
         for (uint32_t c = 0; c < cfg.numIndirect; c++) {               // the loop at rendering.d:474-476
-          uint32_t lane = (c + 1) * wf.capSlots + i;
+          uint32_t lane = (c + 1) * wf.capSlots + laneSlot;
           Rng gc; gc.s0 = 1; gc.s1 = 0;
           if (active) { gc.seed(cfg.seed, gp, sampleIdx, c + 1); wf.Lacc[lane] = make_float4(0, 0, 0, 0); }
           bounce(cx, active, gc, 0, v3(1, 1, 1), color, hitPos, normal, lane, qOut);
         }
       } else {
-        bounce(cx, active, g, depth, T, color, hitPos, normal, laneSlot, qOut);
+        bounce(cx, active, g, depth, Tp, color, hitPos, normal, laneSlot, qOut);
       }
     }
   }
+  __syncthreads();
+  if (threadIdx.x == 0) wf.rayOut.count[T] = sCnt[0];
+  if (threadIdx.x >= 1 && threadIdx.x <= (uint32_t)numKinds) wf.sh[threadIdx.x - 1].count[T] = sCnt[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------ accumulate
@@ -448,7 +571,7 @@ __global__ void __launch_bounds__(512) k_shade(DevScene sc, DevCfg cfg, PixMap p
 __global__ void __launch_bounds__(256) k_accumulate(DevCfg cfg, PixMap pm, float4* __restrict__ acc, Wavefront wf) {
   uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
   if (lp >= pm.npix) return;
-  uint32_t gp = mapPixel(pm, lp);
+  uint32_t gp = mapPixel(pm, cfg.W, lp);
   float4 a = acc[gp];
   for (uint32_t s = 0; s < pm.k; s++) {
     uint32_t slot = s * pm.npix + lp;
@@ -468,7 +591,8 @@ __global__ void __launch_bounds__(256) k_accumulate(DevCfg cfg, PixMap pm, float
 __global__ void k_view_rays(DevCfg cfg, uint32_t pixelOffset, uint32_t count, float* __restrict__ rays6) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
-  float x, y; viewRayXY(pixelOffset + i, cfg.W, cfg.H, nullptr, x, y);
+  uint32_t p = pixelOffset + i, row = fdiv(cfg.divW, p), col = p - row * cfg.W;
+  float x, y; viewRayXY(col, row, cfg.W, cfg.H, nullptr, x, y);
   V3 d = screenRayDir(cfg.cam, x, y);
   float* r = rays6 + 6 * (size_t)i;
   r[0] = cfg.cam.pos.x; r[1] = cfg.cam.pos.y; r[2] = cfg.cam.pos.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
@@ -533,8 +657,8 @@ __global__ void k_rng_stream(uint32_t seed, uint32_t pixel, uint32_t sample, uin
 // ------------------------------------------------------------------------------------------------ launch geometry
 struct Geo { dim3 grid, block; size_t lds; };
 
-// Traversal kernels are persistent: enough workgroups to fill the chip, grid-stride over the queue.
-// With the scene in LDS the workgroup size grows with the scene so that one copy serves many waves.
+// Traversal kernels are persistent: enough workgroups to fill the chip.  With the scene in LDS the workgroup
+// size grows with the scene so that one copy serves many waves.
 Geo traversalGeo(const LaunchCfg& lc, const DevScene& sc, uint64_t maxItems) {
   Geo g; g.lds = sc.ldsBytes;
   uint32_t bs, perCU;
@@ -549,9 +673,13 @@ Geo traversalGeo(const LaunchCfg& lc, const DevScene& sc, uint64_t maxItems) {
   return g;
 }
 
-// Dynamic LDS above 64 KB has to be allowed per kernel (and per device) before the launch.
-template <typename K> void allowLds(K kernel, size_t bytes) {
-  if (bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+// Dynamic LDS above 64 KB has to be allowed per kernel and device, once, before the first launch.
+void allowLds(const LaunchCfg& lc, const void* kernel, size_t bytes) {
+  if (bytes <= 48 * 1024) return;
+  static std::mutex mu; static std::set<std::pair<int, const void*>> done;
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.insert({lc.device, kernel}).second)
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);   // + static LDS <= 160 KB
 }
 
 }  // namespace
@@ -559,11 +687,20 @@ template <typename K> void allowLds(K kernel, size_t bytes) {
 #define PT_DISPATCH_LC(KERNEL, ...)                                                              \
   do {                                                                                           \
     bool l_ = sc.ldsBytes != 0, c_ = lc.countVisits;                                             \
-    if (l_ && c_) { allowLds(KERNEL<true, true>, g.lds); hipLaunchKernelGGL((KERNEL<true, true>), g.grid, g.block, g.lds, lc.stream, __VA_ARGS__); } \
-    else if (l_) { allowLds(KERNEL<true, false>, g.lds); hipLaunchKernelGGL((KERNEL<true, false>), g.grid, g.block, g.lds, lc.stream, __VA_ARGS__); } \
+    if (l_ && c_) { allowLds(lc, (const void*)KERNEL<true, true>, g.lds); hipLaunchKernelGGL((KERNEL<true, true>), g.grid, g.block, g.lds, lc.stream, __VA_ARGS__); } \
+    else if (l_) { allowLds(lc, (const void*)KERNEL<true, false>, g.lds); hipLaunchKernelGGL((KERNEL<true, false>), g.grid, g.block, g.lds, lc.stream, __VA_ARGS__); } \
     else if (c_) hipLaunchKernelGGL((KERNEL<false, true>), g.grid, g.block, 0, lc.stream, __VA_ARGS__);   \
     else hipLaunchKernelGGL((KERNEL<false, false>), g.grid, g.block, 0, lc.stream, __VA_ARGS__);          \
   } while (0)
+
+void launchRaygen(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
+                  uint32_t nslots, const Wavefront& wf, int qOut) {
+  hipLaunchKernelGGL(k_raygen, dim3(PT_SEGS), dim3(256), 0, lc.stream, sc, cfg, pm, acc, nslots, wf, qOut);
+}
+
+void launchScan(const LaunchCfg& lc, const QMeta* metas, int n, uint32_t* taskCounters) {
+  hipLaunchKernelGGL(k_scan, dim3(n), dim3(PT_SEGS), 0, lc.stream, metas, taskCounters);
+}
 
 void launchExtendPrimary(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
                          uint32_t nslots, int jitter, float4* hit, unsigned long long* stats) {
@@ -573,32 +710,29 @@ void launchExtendPrimary(const LaunchCfg& lc, const DevScene& sc, const DevCfg& 
 
 void launchExtendQueue(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int q, int statSlot) {
   Geo g = traversalGeo(lc, sc, wf.capQueue);
-  PT_DISPATCH_LC(k_extend_queue, sc, cfg.eps, (const float4*)wf.rayO[q], (const float4*)wf.rayD[q],
-                 (const uint32_t*)&wf.cntIn[0], wf.hit, wf.stats, statSlot);
+  PT_DISPATCH_LC(k_extend_queue, sc, cfg.eps, wf.rayIn, wf.capQueue / PT_SEGS, (const float4*)wf.rayO[q], (const float4*)wf.rayD[q],
+                 wf.taskCounters + 0, wf.hit, wf.stats, statSlot);
 }
 
 void launchConnect(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, float area) {
   Geo g = traversalGeo(lc, sc, wf.capQueue);
   size_t e = (size_t)kind * wf.capQueue;
-  PT_DISPATCH_LC(k_connect, sc, cfg.eps, (const float4*)(wf.shO + e), (const float4*)(wf.shD + e), (const float4*)(wf.shW + e),
-                 (const uint32_t*)&wf.cntOut[1 + kind], area, wf.Lacc, wf.stats);
+  PT_DISPATCH_LC(k_connect, sc, cfg.eps, wf.sh[kind], wf.capQueue / PT_SEGS, (const float4*)(wf.shO + e), (const float4*)(wf.shD + e),
+                 (const float4*)(wf.shW + e), wf.taskCounters + 1 + kind, area, wf.Lacc, wf.stats);
 }
 
 void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind) {
   Geo g = traversalGeo(lc, sc, wf.capQueue);
   size_t e = (size_t)kind * wf.capQueue;
-  PT_DISPATCH_LC(k_occluded, sc, cfg.eps, (const float4*)(wf.shO + e), (const float4*)(wf.shD + e), (const float4*)(wf.shW + e),
-                 (const uint32_t*)&wf.cntOut[1 + kind], wf.Lacc, wf.stats);
+  PT_DISPATCH_LC(k_occluded, sc, cfg.eps, wf.sh[kind], wf.capQueue / PT_SEGS, (const float4*)(wf.shO + e), (const float4*)(wf.shD + e),
+                 (const float4*)(wf.shW + e), wf.taskCounters + 1 + kind, wf.Lacc, wf.stats);
 }
 
 void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
-                 const Wavefront& wf, bool primary, uint32_t nslots, int qIn, int qOut) {
-  uint32_t bs = 512;
-  uint64_t items = primary ? nslots : wf.capQueue;
-  uint64_t want = (items + bs - 1) / bs, cap = (uint64_t)lc.numCUs * 4;
-  dim3 grid((unsigned)std::max<uint64_t>(1, std::min(want, cap)));
-  if (primary) hipLaunchKernelGGL(k_shade<true>, grid, dim3(bs), 0, lc.stream, sc, cfg, pm, acc, wf, nslots, qIn, qOut);
-  else hipLaunchKernelGGL(k_shade<false>, grid, dim3(bs), 0, lc.stream, sc, cfg, pm, acc, wf, nslots, qIn, qOut);
+                 const Wavefront& wf, bool primary, int qIn, int qOut) {
+  int numKinds = (cfg.hasLights ? (int)sc.numLightGroups : 0) + (cfg.hasSky ? 2 : 0);
+  if (primary) hipLaunchKernelGGL(k_shade<true>, dim3(PT_SEGS), dim3(256), 0, lc.stream, sc, cfg, pm, acc, wf, qIn, qOut, numKinds);
+  else hipLaunchKernelGGL(k_shade<false>, dim3(PT_SEGS), dim3(256), 0, lc.stream, sc, cfg, pm, acc, wf, qIn, qOut, numKinds);
 }
 
 void launchAccumulate(const LaunchCfg& lc, const DevCfg& cfg, const PixMap& pm, float4* acc, const Wavefront& wf) {
@@ -612,13 +746,13 @@ void launchViewRays(const LaunchCfg& lc, const DevCfg& cfg, uint32_t pixelOffset
 void launchTraceRays(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const float* rays6, uint32_t count,
                      int32_t* triId, float* t, float* u, float* v, float* normal3) {
   Geo g = traversalGeo(lc, sc, count);
-  if (sc.ldsBytes) { allowLds(k_trace_rays<true>, g.lds); hipLaunchKernelGGL(k_trace_rays<true>, g.grid, g.block, g.lds, lc.stream, sc, cfg.eps, rays6, count, triId, t, u, v, normal3); }
+  if (sc.ldsBytes) { allowLds(lc, (const void*)k_trace_rays<true>, g.lds); hipLaunchKernelGGL(k_trace_rays<true>, g.grid, g.block, g.lds, lc.stream, sc, cfg.eps, rays6, count, triId, t, u, v, normal3); }
   else hipLaunchKernelGGL(k_trace_rays<false>, g.grid, g.block, 0, lc.stream, sc, cfg.eps, rays6, count, triId, t, u, v, normal3);
 }
 
 void launchHitsNothing(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const float* rays6, uint32_t count, uint8_t* out) {
   Geo g = traversalGeo(lc, sc, count);
-  if (sc.ldsBytes) { allowLds(k_hits_nothing<true>, g.lds); hipLaunchKernelGGL(k_hits_nothing<true>, g.grid, g.block, g.lds, lc.stream, sc, cfg.eps, rays6, count, out); }
+  if (sc.ldsBytes) { allowLds(lc, (const void*)k_hits_nothing<true>, g.lds); hipLaunchKernelGGL(k_hits_nothing<true>, g.grid, g.block, g.lds, lc.stream, sc, cfg.eps, rays6, count, out); }
   else hipLaunchKernelGGL(k_hits_nothing<false>, g.grid, g.block, 0, lc.stream, sc, cfg.eps, rays6, count, out);
 }
 

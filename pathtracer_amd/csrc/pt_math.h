@@ -79,12 +79,12 @@ struct Rng {
   PT_HD float uniform(float a, float b) { return a + (b - a) * u01(); }   // std.random.uniform, "[)"
 };
 
-// getViewRay's screen coordinates, rendering.d:280-283 (x first, then y)
-PT_HD void viewRayXY(uint32_t pixelIndex, uint32_t W, uint32_t H, Rng* gen, float& x, float& y) {
+// getViewRay's screen coordinates, rendering.d:280-283 (x first, then y); col = pixelIndex % W, row = pixelIndex / W
+PT_HD void viewRayXY(uint32_t col, uint32_t row, uint32_t W, uint32_t H, Rng* gen, float& x, float& y) {
   float psx = 1.0f / (float)W, psy = 1.0f / (float)H;
-  x = (float)(pixelIndex % W) / (float)W * 2.0f - 1.0f;
+  x = (float)col / (float)W * 2.0f - 1.0f;
   if (gen) x = x + gen->uniform(-psx, psx);
-  y = (float)(pixelIndex / W) / (float)H * 2.0f - 1.0f;
+  y = (float)row / (float)H * 2.0f - 1.0f;
   if (gen) y = y + gen->uniform(-psy, psy);
 }
 
