@@ -57,7 +57,8 @@ struct PtHandle {
   DevScene dsc{};
   DevBuf accOwn; float4* acc = nullptr; uint64_t accBytes = 0;
   // wavefront buffers
-  DevBuf bHit, bRayO[2], bRayD[2], bLacc, bThr, bRng, bShO, bShD, bShW, bCounters, bStats;
+  DevBuf bSlotQ, bHitA, bHitB, bRayO, bRayD, bLacc, bThr, bRng, bShO, bShD, bShW, bCounters, bStats;
+  CullBoxes cull{};
   DevBuf bMetaDesc; std::vector<QMeta> metas;     // queue descriptors: device copy and host copy, stage-major
   Wavefront wf{}; uint32_t wfKinds = 0, wfRounds = 0;
   // statistics
@@ -205,7 +206,30 @@ void uploadScene(PtHandle* h) {
   d.lightArea = h->dLightArea.as<float>();
   d.numNodes = bvh.numNodes; d.numTris = NT; d.numOrigTris = T; d.rootRef = bvh.rootRef;
   d.numLightGroups = (uint32_t)lt.numGroups();
-  d.boxMin = v3(bvh.nodes[0], bvh.nodes[1], bvh.nodes[2]); d.boxMax = v3(bvh.nodes[4], bvh.nodes[5], bvh.nodes[6]);
+  {  // a cut through the top of the tree: repeatedly replace the largest internal box by its two children
+    struct Item { uint32_t node; float area; };
+    std::vector<Item> cut;
+    auto area = [&](uint32_t n) { const float* b = &bvh.nodes[(size_t)n * 8];
+                                  float dx = b[4] - b[0], dy = b[5] - b[1], dz = b[6] - b[2]; return dx * dy + dy * dz + dz * dx; };
+    auto refOf = [&](uint32_t n) { uint32_t r; std::memcpy(&r, &bvh.nodes[(size_t)n * 8 + 3], 4); return r; };
+    cut.push_back(Item{0, area(0)});
+    while (cut.size() < (size_t)PT_CULL_BOXES - 1) {
+      int best = -1;
+      for (size_t i = 0; i < cut.size(); i++)
+        if ((refOf(cut[i].node) >> BVH_COUNT_SHIFT) == 0 && (best < 0 || cut[i].area > cut[best].area)) best = (int)i;
+      if (best < 0) break;
+      uint32_t pair = refOf(cut[best].node) & BVH_INDEX_MASK;
+      cut[best] = Item{2 * pair, area(2 * pair)};
+      cut.push_back(Item{2 * pair + 1, area(2 * pair + 1)});
+    }
+    // box 0 is the root (most rays are decided by it alone); the cut follows unless it is the root itself
+    if (cut.size() == 1) cut.clear();
+    h->cull.count = (uint32_t)cut.size() + 1;
+    for (size_t i = 0; i <= cut.size(); i++) {
+      const float* b = &bvh.nodes[(size_t)(i ? cut[i - 1].node : 0) * 8];
+      for (int k = 0; k < 3; k++) { h->cull.mn[i][k] = b[k]; h->cull.mx[i][k] = b[4 + k]; }
+    }
+  }
   size_t ldsNeed = ((size_t)2 * bvh.numNodes + (size_t)3 * NT) * 16;
   d.ldsBytes = (!(h->cfg.flags & PT_FLAG_NO_LDS_SCENE) && ldsNeed <= 156 * 1024) ? (uint32_t)ldsNeed : 0;
   h->haveScene = true;
@@ -234,17 +258,18 @@ void ensureWavefront(PtHandle* h) {
   Wavefront& w = h->wf;
   if (w.capSlots == capSlots && w.capQueue == (uint32_t)capQueue && w.lanes == lanes && h->wfKinds == kinds && h->wfRounds == rounds) return;
   HIPCHECK(hipStreamSynchronize(h->stream));
-  h->bHit.alloc(capQueue * 16);
-  // queue 0 always carries the view rays that entered the scene's box; queue 1 only exists with indirect rays
-  for (int q = 0; q < 2; q++) { h->bRayO[q].alloc(NI || q == 0 ? capQueue * 16 : 16); h->bRayD[q].alloc(NI || q == 0 ? capQueue * 16 : 16); }
+  h->bSlotQ.alloc((uint64_t)capSlots * 16);
+  h->bHitA.alloc(capQueue * 16); h->bHitB.alloc(capQueue * 16);
+  h->bRayO.alloc(NI ? capQueue * 16 : 16); h->bRayD.alloc(NI ? capQueue * 16 : 16);      // indirect rays only
   h->bLacc.alloc((uint64_t)lanes * capSlots * 16);
   h->bThr.alloc(NI ? (uint64_t)lanes * capSlots * 16 : 16);
   h->bRng.alloc(NI ? (uint64_t)lanes * capSlots * 8 : 16);
   h->bShO.alloc((uint64_t)kinds * capQueue * 16);
   h->bShD.alloc((uint64_t)kinds * capQueue * 16);
   h->bShW.alloc((uint64_t)kinds * capQueue * 16);
-  // queue bookkeeping: stage s owns 1 + PT_MAX_KINDS queues (ray queue it fills, its shadow queues)
-  const uint32_t perStage = 1 + PT_MAX_KINDS;
+  // queue bookkeeping: stage s owns 2 + PT_MAX_KINDS queues: [0] the hit queue its extend fills, [1] the ray queue
+  // and [2 + kind] the shadow queues its shade fills
+  const uint32_t perStage = 2 + PT_MAX_KINDS;
   h->bCounters.alloc((size_t)rounds * perStage * PT_QMETA_WORDS * 4 + PT_TASK_COUNTERS * 4);
   h->bMetaDesc.alloc((size_t)rounds * perStage * sizeof(QMeta));
   h->metas.resize((size_t)rounds * perStage);
@@ -256,8 +281,8 @@ void ensureWavefront(PtHandle* h) {
   HIPCHECK(hipMemset(h->bCounters.p, 0, h->bCounters.bytes));
   HIPCHECK(hipMemcpy(h->bMetaDesc.p, h->metas.data(), h->metas.size() * sizeof(QMeta), hipMemcpyHostToDevice));
   w.taskCounters = words + h->metas.size() * PT_QMETA_WORDS;
-  w.hit = h->bHit.as<float4>();
-  for (int q = 0; q < 2; q++) { w.rayO[q] = h->bRayO[q].as<float4>(); w.rayD[q] = h->bRayD[q].as<float4>(); }
+  w.slotQ = h->bSlotQ.as<float4>(); w.hitA = h->bHitA.as<float4>(); w.hitB = h->bHitB.as<float4>();
+  w.rayO = h->bRayO.as<float4>(); w.rayD = h->bRayD.as<float4>();
   w.Lacc = h->bLacc.as<float4>(); w.thr = h->bThr.as<float4>(); w.rng = h->bRng.as<uint2>();
   w.shO = h->bShO.as<float4>(); w.shD = h->bShD.as<float4>(); w.shW = h->bShW.as<float4>();
   w.stats = h->bStats.as<unsigned long long>();
@@ -280,40 +305,37 @@ void launchShadowKinds(PtHandle* h, const LaunchCfg& lc, const DevCfg& dc, const
 // view-ray hits, 2 + r = shading of the indirect hits of round r; a stage reads the ray queue its predecessor filled.
 void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm) {
   Wavefront wf = h->wf;
-  const uint32_t perStage = 1 + PT_MAX_KINDS;
+  const uint32_t perStage = 2 + PT_MAX_KINDS;
   const int kinds = (int)((dc.hasLights ? h->dsc.numLightGroups : 0) + (dc.hasSky ? 2 : 0));
   const QMeta* desc = h->bMetaDesc.as<QMeta>();
-  // stage s: 0 = raygen, 1 = shading of the view-ray hits, 2 + r = shading of the indirect hits of round r.
-  // A stage fills its own ray queue and shadow queues; the scan after it makes them readable.
+  // stage s: 0 = raygen, 1 = view-ray hits, 2 + r = indirect hits of round r.  Per stage: extend reads the previous
+  // stage's ray queue and fills the hit queue [0]; shade reads it and fills the ray queue [1] and shadow queues
+  // [2 + kind]; a scan after each producer makes its queues readable.
   auto bind = [&](uint32_t stage) {
-    wf.rayIn = h->metas[(size_t)(stage - 1) * perStage];
-    wf.rayOut = h->metas[(size_t)stage * perStage];
-    for (int k = 0; k < PT_MAX_KINDS; k++) wf.sh[k] = h->metas[(size_t)stage * perStage + 1 + k];
+    wf.rayIn = h->metas[(size_t)(stage - 1) * perStage + 1];
+    wf.hitQ = h->metas[(size_t)stage * perStage];
+    wf.rayOut = h->metas[(size_t)stage * perStage + 1];
+    for (int k = 0; k < PT_MAX_KINDS; k++) wf.sh[k] = h->metas[(size_t)stage * perStage + 2 + k];
   };
-  auto scan = [&](uint32_t stage, int n) {
-    Timed t(h, PT_K_OTHER); launchScan(lc, desc + (size_t)stage * perStage, n, wf.taskCounters); t.done();
+  auto scan = [&](size_t first, int n) {
+    Timed t(h, PT_K_OTHER); launchScan(lc, desc + first, n, wf.taskCounters); t.done();
+  };
+  auto stage = [&](uint32_t s, bool primary) {
+    bind(s);
+    { Timed t(h, PT_K_EXTEND); launchExtend(lc, h->dsc, dc, pm, h->acc, wf, primary); t.done(); }
+    scan((size_t)s * perStage, 1);
+    { Timed t(h, PT_K_SHADE); launchShade(lc, h->dsc, dc, pm, h->acc, wf, primary); t.done(); }
+    scan((size_t)s * perStage + 1, 1 + kinds);
+    launchShadowKinds(h, lc, dc, wf);
   };
   uint32_t nslots = pm.npix * pm.k;
-  wf.rayOut = h->metas[0];
-  { Timed t(h, PT_K_OTHER); launchRaygen(lc, h->dsc, dc, pm, h->acc, nslots, wf, 0); t.done(); }
-  scan(0, 1);
-  bind(1);
-  { Timed t(h, PT_K_EXTEND); launchExtendQueue(lc, h->dsc, dc, wf, 0, -1); t.done(); }
-  { Timed t(h, PT_K_SHADE); launchShade(lc, h->dsc, dc, pm, h->acc, wf, true, 0, 1); t.done(); }
-  scan(1, 1 + kinds);
-  launchShadowKinds(h, lc, dc, wf);
+  wf.rayOut = h->metas[1];
+  { Timed t(h, PT_K_OTHER); launchRaygen(lc, h->cull, dc, pm, h->acc, nslots, wf); t.done(); }
+  scan(1, 1);
+  stage(1, true);
   h->st.raysPrimary += nslots; h->st.samples += nslots;
-  if (dc.mode == 1) {
-    // depth 0..maxDepth can still spawn a ray (the check is depth > maxDepth, rendering.d:380)
-    for (uint32_t round = 0; round <= dc.maxDepth; round++) {
-      int qIn = (round + 1) & 1, qOut = qIn ^ 1;
-      bind(round + 2);
-      { Timed t(h, PT_K_EXTEND); launchExtendQueue(lc, h->dsc, dc, wf, qIn, STAT_RAYS_INDIRECT); t.done(); }
-      { Timed t(h, PT_K_SHADE); launchShade(lc, h->dsc, dc, pm, h->acc, wf, false, qIn, qOut); t.done(); }
-      scan(round + 2, 1 + kinds);
-      launchShadowKinds(h, lc, dc, wf);
-    }
-  }
+  if (dc.mode == 1)      // depth 0..maxDepth can still spawn a ray (the check is depth > maxDepth, rendering.d:380)
+    for (uint32_t round = 0; round <= dc.maxDepth; round++) stage(round + 2, false);
   { Timed t(h, PT_K_ACCUM); launchAccumulate(lc, dc, pm, h->acc, wf); t.done(); }
   HIPCHECK(hipGetLastError());
 }

@@ -37,8 +37,12 @@ struct DevScene {
   const float* lightArea;     // g_totalLightSourceArea
   uint32_t numNodes, numTris, numOrigTris, rootRef, numLightGroups;
   uint32_t ldsBytes;          // 0 => traverse from global memory
-  V3 boxMin, boxMax;          // padded bounds of the whole scene (the root node's box)
 };
+
+// The boxes of the BVH's top levels (a cut through the tree: every triangle is inside one of them).  A view ray
+// that misses all of them cannot hit anything; raygen answers it without a traversal.
+constexpr int PT_CULL_BOXES = 16;
+struct CullBoxes { float mn[PT_CULL_BOXES][3]; float mx[PT_CULL_BOXES][3]; uint32_t count; };
 
 struct DevCfg {               // PtConfig + camera as the kernels need them
   uint32_t W, H, mode, hasSky, hasLights;
@@ -94,18 +98,21 @@ constexpr uint32_t PT_QMETA_WORDS = 3 * PT_SEGS + 2;
 constexpr int PT_TASK_COUNTERS = 16;   // one dynamic block-task counter per traversal launch of a stage
 
 struct Wavefront {
-  float4* hit;                // per flat ray-queue entry: (t, u, v, triId)
-  float4* rayO[2];            // ray queues (ping-pong): (origin.xyz, lane slot)
-  float4* rayD[2];            //                          (dir.xyz, 0)
+  float4* slotQ;              // view rays that may hit something: (dir.xyz, path slot); the origin is the camera
+  float4* rayO;               // indirect-ray queue: (origin.xyz, lane slot)
+  float4* rayD;               //                     (dir.xyz, 0)
+  float4* hitA;               // hit queue (filled by extend, hits only): (hit position.xyz, triangle id)
+  float4* hitB;               //                                          (u, v, lane slot, t)
   float4* Lacc;               // per lane slot: radiance gathered by this lane (xyz), primary-hit flag (w)
   float4* thr;                // per lane slot: throughput of the chain (xyz), depth (w)
   uint2* rng;                 // per lane slot: generator state
   float4* shO;                // shadow queues, kind-major: (origin.xyz, lane slot)
   float4* shD;                //                            (dir.xyz, light distance)
   float4* shW;                //                            (weight.xyz, n.omega)
-  QMeta rayIn;                // ray queue this stage reads
-  QMeta rayOut;               // ray queue this stage fills
-  QMeta sh[PT_MAX_KINDS];     // shadow queues of this stage
+  QMeta rayIn;                // slot / ray queue this stage's extend reads (filled by the previous stage)
+  QMeta hitQ;                 // hit queue of this stage: extend fills it, shade reads it
+  QMeta rayOut;               // ray queue this stage's shade fills
+  QMeta sh[PT_MAX_KINDS];     // shadow queues this stage's shade fills
   uint32_t* taskCounters;     // [PT_TASK_COUNTERS], zeroed by the scan that precedes the launches using them
   unsigned long long* stats;  // see STAT_*
   uint32_t capSlots;          // primary slots per batch (multiple of 64 * PT_SEGS)
@@ -119,13 +126,15 @@ enum { STAT_RAYS_LIGHT = 0, STAT_RAYS_INDIRECT, STAT_RAYS_OCCL, STAT_NODES_CLOSE
 struct LaunchCfg { int device; int numCUs; bool countVisits; hipStream_t stream; };
 
 // ---- wavefront stages (all asynchronous on lc.stream) ----
-void launchRaygen(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
-                  uint32_t nslots, const Wavefront& wf, int qOut);
+void launchRaygen(const LaunchCfg& lc, const CullBoxes& cull, const DevCfg& cfg, const PixMap& pm, const float4* acc,
+                  uint32_t nslots, const Wavefront& wf);
 // prefix sums + consumer start segments for n queues, and zeroing of the stage's dynamic task counters
 void launchScan(const LaunchCfg& lc, const QMeta* metas, int n, uint32_t* taskCounters);
-void launchExtendQueue(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int q, int statSlot);
+// primary: entries of wf.rayIn index wf.slotQ (view direction + path slot); else wf.rayO / wf.rayD
+void launchExtend(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
+                  const Wavefront& wf, bool primary);
 void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
-                 const Wavefront& wf, bool primary, int qIn, int qOut);
+                 const Wavefront& wf, bool primary);
 void launchConnect(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, float area);
 void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind);
 void launchAccumulate(const LaunchCfg& lc, const DevCfg& cfg, const PixMap& pm, float4* acc, const Wavefront& wf);

@@ -103,13 +103,13 @@ __device__ __forceinline__ bool traverse(const DevScene& sc, V3 o, V3 d, float e
       bool h0 = slab(ri, a0.x, a0.y, a0.z, a1.x, a1.y, a1.z, h.t, tn0);
       bool h1 = slab(ri, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, h.t, tn1);
       uint32_t r0 = f2u(a0.w), r1 = f2u(b0.w);
-      if (h0 && h1) {
-        bool sw = tn1 < tn0;
-        stack[sp++] = sw ? r0 : r1;
-        ref = sw ? r1 : r0;
-      } else if (h0 || h1) {
-        ref = h0 ? r0 : r1;
-      } else {
+      // near child first; selects instead of a three-way branch (the exec-mask bookkeeping of nested branches
+      // cost as many scalar instructions as the two box tests cost vector instructions)
+      bool sw = h1 && (!h0 || tn1 < tn0);
+      uint32_t nearRef = sw ? r1 : r0, farRef = sw ? r0 : r1;
+      if (h0 && h1) stack[sp++] = farRef;
+      if (h0 || h1) ref = nearRef;
+      else {
         if (sp == 0) { live = false; break; }
         ref = stack[--sp];
       }
@@ -215,11 +215,12 @@ __global__ void __launch_bounds__(1024) k_scan(const QMeta* __restrict__ metas, 
 }
 
 // Dynamic block-task distribution for the persistent traversal kernels (PT_SEGS atomics per launch).
+// sTask[0] = task, sTask[1] = the workgroup's append counter for the task (reset here, between the barriers).
 __device__ __forceinline__ bool nextTask(uint32_t* counter, uint32_t* sTask, uint32_t& T) {
   __syncthreads();
-  if (threadIdx.x == 0) *sTask = atomicAdd(counter, 1u);
+  if (threadIdx.x == 0) { sTask[0] = atomicAdd(counter, 1u); sTask[1] = 0; }
   __syncthreads();
-  T = *sTask;
+  T = sTask[0];
   return T < PT_SEGS;
 }
 
@@ -245,32 +246,35 @@ __device__ __forceinline__ PrimaryRay primaryRay(const DevCfg& cfg, const PixMap
 }
 
 // ------------------------------------------------------------------------------------------------ raygen
-// Block-task T = blockIdx.x covers slots [T*P, (T+1)*P); the rays that enter the scene's box go to segment T.
-__global__ void __launch_bounds__(256) k_raygen(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, uint32_t nslots,
-                                                Wavefront wf, int qOut) {
+// Block-task T = blockIdx.x covers slots [T*P, (T+1)*P).  A view ray that misses every box of the BVH's top cut
+// cannot hit anything: its sample is finished here (sampleSky).  The others are queued as (direction, slot), 16 B:
+// the origin is the camera position and everything else is a function of the slot.  The boxes are kernel
+// arguments, i.e. scalar registers: the test costs no memory traffic.
+__global__ void __launch_bounds__(256) k_raygen(CullBoxes cull, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, uint32_t nslots,
+                                                Wavefront wf) {
   __shared__ uint32_t sCnt;
   if (threadIdx.x == 0) sCnt = 0;
   __syncthreads();
   uint32_t T = blockIdx.x, P = dense64(nslots), begin = T * P, end = min(begin + P, nslots);
-  uint32_t segCap = wf.capQueue / PT_SEGS, culled = 0;
+  uint32_t segCap = wf.capSlots / PT_SEGS, culled = 0;
   for (uint32_t base = begin; base < end; base += blockDim.x) {
     uint32_t i = base + threadIdx.x;
     bool enter = false;
     V3 d = v3(0, 0, 0);
     if (i < end) {
-      PrimaryRay pr = primaryRay(cfg, pm, acc, i, true);
-      d = pr.d;
+      d = primaryRay(cfg, pm, acc, i, true).d;
       RayInv ri = makeRayInv(cfg.cam.pos, d);
       float tn;
-      enter = slab(ri, sc.boxMin.x, sc.boxMin.y, sc.boxMin.z, sc.boxMax.x, sc.boxMax.y, sc.boxMax.z, PT_FLT_MAX, tn);
-      if (!enter) { wf.Lacc[i] = f4(sampleSky(d), 0.0f); culled++; }         // rendering.d:480
+      // box 0 is the whole scene; only rays that enter it are tested against the boxes of the cut
+      if (slab(ri, cull.mn[0][0], cull.mn[0][1], cull.mn[0][2], cull.mx[0][0], cull.mx[0][1], cull.mx[0][2], PT_FLT_MAX, tn)) {
+        enter = cull.count <= 1;
+        for (uint32_t b = 1; b < cull.count; b++)
+          enter = enter || slab(ri, cull.mn[b][0], cull.mn[b][1], cull.mn[b][2], cull.mx[b][0], cull.mx[b][1], cull.mx[b][2], PT_FLT_MAX, tn);
+      }
+      if (!enter) { wf.Lacc[i] = f4(sampleSky(d), 0.0f); culled++; }          // rendering.d:480
     }
     uint32_t idx = waveAppend(enter, &sCnt);
-    if (enter) {
-      uint32_t e = T * segCap + idx;
-      wf.rayO[qOut][e] = f4(cfg.cam.pos, u2f(i));
-      wf.rayD[qOut][e] = f4(d, 0.0f);
-    }
+    if (enter) wf.slotQ[T * segCap + idx] = f4(d, u2f(i));
   }
   for (int off = 32; off > 0; off >>= 1) culled += __shfl_down(culled, off);
   if ((threadIdx.x & 63) == 0 && culled) atomicAdd(&wf.stats[STAT_RAYS_CULLED], (unsigned long long)culled);
@@ -279,27 +283,50 @@ __global__ void __launch_bounds__(256) k_raygen(DevScene sc, DevCfg cfg, PixMap 
 }
 
 // ------------------------------------------------------------------------------------------------ extend
-// Closest hit for every entry of a ray queue; hit[] is indexed by the flat entry number.
-template <bool LDSS, bool COUNT>
-__global__ void __launch_bounds__(1024) k_extend_queue(DevScene sc, float eps, QMeta q, uint32_t segCap, const float4* __restrict__ rayO,
-                                                       const float4* __restrict__ rayD, uint32_t* taskCounter,
-                                                       float4* __restrict__ hit, unsigned long long* stats, int statSlot) {
+// Scene.trace for every entry of the input queue.  PRIMARY: entries are (view direction, path slot) and a
+// miss finishes the sample (sampleSky, rendering.d:480).  Otherwise entries are stored indirect rays and a miss ends
+// the chain (rendering.d:393).  Hits -- and only hits -- are appended to the hit queue, with the hit position
+// (Ray.get(rayPos), rendering.d:390,472) so that shading never needs the ray again.
+template <bool PRIMARY, bool LDSS, bool COUNT>
+__global__ void __launch_bounds__(1024) k_extend(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, Wavefront wf) {
   __shared__ __align__(16) uint32_t sTask[4];
   stageScene<LDSS>(sc);
   uint32_t cN = 0, cT = 0, T;
-  if (statSlot >= 0 && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[statSlot], (unsigned long long)q.prefix[PT_SEGS]);
-  while (nextTask(taskCounter, sTask, T)) {
+  const QMeta q = wf.rayIn;
+  const uint32_t segCapIn = (PRIMARY ? wf.capSlots : wf.capQueue) / PT_SEGS, segCapOut = wf.capQueue / PT_SEGS;
+  if (!PRIMARY && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&wf.stats[STAT_RAYS_INDIRECT], (unsigned long long)q.prefix[PT_SEGS]);
+  while (nextTask(wf.taskCounters, sTask, T)) {
     Task tk = taskOf(q, T);
     uint32_t seg = tk.seg;
-    for (uint32_t j = tk.begin + threadIdx.x; j < tk.end; j += blockDim.x) {
-      uint32_t e = physIndex(q, j, seg, segCap);
-      float4 ro = rayO[e], rd = rayD[e];
-      Hit h;
-      traverse<false, LDSS, COUNT>(sc, xyz(ro), xyz(rd), eps, h, cN, cT);
-      hit[j] = make_float4(h.t, h.u, h.v, u2f(h.tri));
+    for (uint32_t base = tk.begin; base < tk.end; base += blockDim.x) {
+      uint32_t j = base + threadIdx.x;
+      bool isHit = false;
+      V3 hitPos = v3(0, 0, 0); Hit h; h.t = 0; h.u = 0; h.v = 0; h.tri = 0; uint32_t slot = 0;
+      if (j < tk.end) {
+        uint32_t e = physIndex(q, j, seg, segCapIn);
+        V3 o, d;
+        if (PRIMARY) {
+          float4 sd = wf.slotQ[e];
+          o = cfg.cam.pos; d = xyz(sd); slot = f2u(sd.w);
+        } else {
+          float4 ro = wf.rayO[e], rd = wf.rayD[e];
+          o = xyz(ro); d = xyz(rd); slot = f2u(ro.w);
+        }
+        isHit = traverse<false, LDSS, COUNT>(sc, o, d, cfg.eps, h, cN, cT);
+        if (isHit) hitPos = o + d * h.t;
+        else if (PRIMARY) wf.Lacc[slot] = f4(sampleSky(d), 0.0f);
+      }
+      uint32_t idx = waveAppend(isHit, &sTask[1]);
+      if (isHit) {
+        uint32_t e = T * segCapOut + idx;
+        wf.hitA[e] = f4(hitPos, u2f(h.tri));
+        wf.hitB[e] = make_float4(h.u, h.v, u2f(slot), h.t);
+      }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) wf.hitQ.count[T] = sTask[1];
   }
-  flushCounts<COUNT>(stats, STAT_NODES_CLOSEST, cN, cT);
+  flushCounts<COUNT>(wf.stats, STAT_NODES_CLOSEST, cN, cT);
 }
 
 // View rays generated in registers, no cull, no queue: the parity probe (getViewRay without jitter + Scene.trace).
@@ -396,7 +423,7 @@ struct ShadeCtx {
 
 // One computeLindirect head (rendering.d:378-385): Russian roulette, direction, ray; appended to ray queue qOut.
 __device__ __forceinline__ void bounce(ShadeCtx& cx, bool active, Rng& g, uint32_t depth, V3 T, V3 color, V3 pos, V3 normal,
-                                       uint32_t laneSlot, int qOut) {
+                                       uint32_t laneSlot) {
   bool alive = false; V3 dir = v3(0, 0, 0);
   if (active) {
     float a = g.uniform(0.0f, 1.0f);
@@ -410,8 +437,8 @@ __device__ __forceinline__ void bounce(ShadeCtx& cx, bool active, Rng& g, uint32
   uint32_t idx = waveAppend(alive, &cx.sCnt[0]);
   if (alive) {
     uint32_t e = cx.T * cx.segCapRay + idx;
-    cx.wf.rayO[qOut][e] = f4(pos + normal * 0.1f, u2f(laneSlot));
-    cx.wf.rayD[qOut][e] = f4(dir, 0.0f);
+    cx.wf.rayO[e] = f4(pos + normal * 0.1f, u2f(laneSlot));
+    cx.wf.rayD[e] = f4(dir, 0.0f);
     // BRDF * PI * color == color: the factor the caller multiplies computeLrefl with (rendering.d:391)
     cx.wf.thr[laneSlot] = f4(T * color, u2f(depth + 1));
     cx.wf.rng[laneSlot] = make_uint2(g.s0, g.s1);
@@ -487,63 +514,51 @@ __device__ __forceinline__ void directLight(ShadeCtx& cx, bool active, Rng& g, V
   }
 }
 
-// PRIMARY: the part of computeL after the view-ray trace (rendering.d:471-481) for the view rays that entered the
-// scene's box; the generator of (pixel, sample) is re-seeded and stepped past the two jitter draws.
-// !PRIMARY: the part of computeLindirect after its trace (rendering.d:389-392) = computeLrefl at the hit.
-// Block-task T = blockIdx.x reads flat entries [T*P, (T+1)*P) of the input ray queue and fills segment T of the
+// PRIMARY: the part of computeL after the view-ray trace has hit (rendering.d:472-477); the generator of
+// (pixel, sample) is re-seeded and stepped past the two jitter draws of getViewRay.
+// !PRIMARY: the part of computeLindirect after its trace has hit (rendering.d:390-391) = computeLrefl at the hit.
+// Block-task T = blockIdx.x reads flat entries [T*P, (T+1)*P) of the hit queue and fills segment T of the
 // output queues.
 template <bool PRIMARY>
 __global__ void __launch_bounds__(256) k_shade(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, Wavefront wf,
-                                               int qIn, int qOut, int numKinds) {
+                                               int numKinds) {
   __shared__ uint32_t sCnt[1 + PT_MAX_KINDS];
   if (threadIdx.x <= PT_MAX_KINDS) sCnt[threadIdx.x] = 0;
   __syncthreads();
   uint32_t T = blockIdx.x;
-  uint32_t segCapIn = wf.capQueue / PT_SEGS;
-  ShadeCtx cx{sc, cfg, wf, sCnt, T, wf.capQueue / PT_SEGS, wf.capQueue / PT_SEGS};
-  Task tk = taskOf(wf.rayIn, T);
+  uint32_t segCap = wf.capQueue / PT_SEGS;
+  ShadeCtx cx{sc, cfg, wf, sCnt, T, segCap, segCap};
+  Task tk = taskOf(wf.hitQ, T);
   uint32_t seg = tk.seg;
   for (uint32_t base = tk.begin; base < tk.end; base += blockDim.x) {
     uint32_t j = base + threadIdx.x;
-    bool valid = j < tk.end, isHit = false;
-    V3 o = v3(0, 0, 0), d = v3(0, 0, 0), Tp = v3(1, 1, 1);
+    bool active = j < tk.end;
+    V3 Tp = v3(1, 1, 1), hitPos = v3(0, 0, 0), normal = v3(0, 0, 1), color = v3(0, 0, 0);
     uint32_t laneSlot = 0, depth = 0, gp = 0, sampleIdx = 0;
     Rng g; g.s0 = 1; g.s1 = 0;
-    float4 hr = make_float4(0, 0, 0, 0);
-    if (valid) {
-      uint32_t e = physIndex(wf.rayIn, j, seg, segCapIn);
-      hr = wf.hit[j];
-      isHit = f2u(hr.w) != 0xFFFFFFFFu;
-      float4 ro = wf.rayO[qIn][e], rd = wf.rayD[qIn][e];
-      o = xyz(ro); d = xyz(rd); laneSlot = f2u(ro.w);
-      if (isHit) {
-        if (PRIMARY) {
-          uint32_t s = fdiv(pm.divNpix, laneSlot), lp = laneSlot - s * pm.npix;
-          gp = mapPixel(pm, cfg.W, lp);
-          sampleIdx = cfg.sampleBase + (uint32_t)acc[gp].w + s;
-          g.seed(cfg.seed, gp, sampleIdx, 0);
-          g.next(); g.next();                                          // the x and y jitter of getViewRay
-        } else {
-          float4 t4 = wf.thr[laneSlot]; Tp = xyz(t4); depth = f2u(t4.w);
-          uint2 r = wf.rng[laneSlot]; g.s0 = r.x; g.s1 = r.y;
-        }
-      }
-    }
-    bool active = valid && isHit;
-    V3 hitPos = v3(0, 0, 0), normal = v3(0, 0, 1), color = v3(0, 0, 0);
     if (active) {
-      uint32_t tri = f2u(hr.w);
+      uint32_t e = physIndex(wf.hitQ, j, seg, segCap);
+      float4 ha = wf.hitA[e], hb = wf.hitB[e];
+      hitPos = xyz(ha); laneSlot = f2u(hb.z);
+      uint32_t tri = f2u(ha.w);
+      if (PRIMARY) {
+        uint32_t s = fdiv(pm.divNpix, laneSlot), lp = laneSlot - s * pm.npix;
+        gp = mapPixel(pm, cfg.W, lp);
+        sampleIdx = cfg.sampleBase + (uint32_t)acc[gp].w + s;
+        g.seed(cfg.seed, gp, sampleIdx, 0);
+        g.next(); g.next();                                            // the x and y jitter of getViewRay
+      } else {
+        float4 t4 = wf.thr[laneSlot]; Tp = xyz(t4); depth = f2u(t4.w);
+        uint2 r = wf.rng[laneSlot]; g.s0 = r.x; g.s1 = r.y;
+      }
       float4 q0 = sc.nrm[3 * tri], q1 = sc.nrm[3 * tri + 1], q2 = sc.nrm[3 * tri + 2];
-      normal = interpNormal(xyz(q0), xyz(q1), xyz(q2), hr.y, hr.z);
-      hitPos = o + d * hr.x;                                           // Ray.get(rayPos)
+      normal = interpNormal(xyz(q0), xyz(q1), xyz(q2), hb.x, hb.y);
       float4 m = sc.mats[f2u(q0.w)];
       color = v3(m.y, m.z, m.w);
       if (PRIMARY) {
-        V3 e = m.x * color;                                            // emissive * color, rendering.d:477
-        wf.Lacc[laneSlot] = f4(e, 1.0f);
+        V3 em = m.x * color;                                           // emissive * color, rendering.d:477
+        wf.Lacc[laneSlot] = f4(em, 1.0f);
       }
-    } else if (valid && PRIMARY) {
-      wf.Lacc[laneSlot] = f4(sampleSky(d), 0.0f);                      // rendering.d:480
     }
     V3 Tw = Tp * (PT_BRDF * color);
     directLight(cx, active, g, hitPos, normal, Tw, laneSlot);
@@ -553,10 +568,10 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, DevCfg cfg, PixMap p
           uint32_t lane = (c + 1) * wf.capSlots + laneSlot;
           Rng gc; gc.s0 = 1; gc.s1 = 0;
           if (active) { gc.seed(cfg.seed, gp, sampleIdx, c + 1); wf.Lacc[lane] = make_float4(0, 0, 0, 0); }
-          bounce(cx, active, gc, 0, v3(1, 1, 1), color, hitPos, normal, lane, qOut);
+          bounce(cx, active, gc, 0, v3(1, 1, 1), color, hitPos, normal, lane);
         }
       } else {
-        bounce(cx, active, g, depth, Tp, color, hitPos, normal, laneSlot, qOut);
+        bounce(cx, active, g, depth, Tp, color, hitPos, normal, laneSlot);
       }
     }
   }
@@ -693,9 +708,9 @@ void allowLds(const LaunchCfg& lc, const void* kernel, size_t bytes) {
     else hipLaunchKernelGGL((KERNEL<false, false>), g.grid, g.block, 0, lc.stream, __VA_ARGS__);          \
   } while (0)
 
-void launchRaygen(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
-                  uint32_t nslots, const Wavefront& wf, int qOut) {
-  hipLaunchKernelGGL(k_raygen, dim3(PT_SEGS), dim3(256), 0, lc.stream, sc, cfg, pm, acc, nslots, wf, qOut);
+void launchRaygen(const LaunchCfg& lc, const CullBoxes& cull, const DevCfg& cfg, const PixMap& pm, const float4* acc,
+                  uint32_t nslots, const Wavefront& wf) {
+  hipLaunchKernelGGL(k_raygen, dim3(PT_SEGS), dim3(256), 0, lc.stream, cull, cfg, pm, acc, nslots, wf);
 }
 
 void launchScan(const LaunchCfg& lc, const QMeta* metas, int n, uint32_t* taskCounters) {
@@ -708,10 +723,20 @@ void launchExtendPrimary(const LaunchCfg& lc, const DevScene& sc, const DevCfg& 
   PT_DISPATCH_LC(k_extend_primary, sc, cfg, pm, acc, nslots, jitter, hit, stats);
 }
 
-void launchExtendQueue(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int q, int statSlot) {
+template <bool PRIMARY>
+static void dispatchExtend(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
+                           const Wavefront& wf) {
   Geo g = traversalGeo(lc, sc, wf.capQueue);
-  PT_DISPATCH_LC(k_extend_queue, sc, cfg.eps, wf.rayIn, wf.capQueue / PT_SEGS, (const float4*)wf.rayO[q], (const float4*)wf.rayD[q],
-                 wf.taskCounters + 0, wf.hit, wf.stats, statSlot);
+  bool l_ = sc.ldsBytes != 0, c_ = lc.countVisits;
+  if (l_ && c_) { allowLds(lc, (const void*)k_extend<PRIMARY, true, true>, g.lds); hipLaunchKernelGGL((k_extend<PRIMARY, true, true>), g.grid, g.block, g.lds, lc.stream, sc, cfg, pm, acc, wf); }
+  else if (l_) { allowLds(lc, (const void*)k_extend<PRIMARY, true, false>, g.lds); hipLaunchKernelGGL((k_extend<PRIMARY, true, false>), g.grid, g.block, g.lds, lc.stream, sc, cfg, pm, acc, wf); }
+  else if (c_) hipLaunchKernelGGL((k_extend<PRIMARY, false, true>), g.grid, g.block, 0, lc.stream, sc, cfg, pm, acc, wf);
+  else hipLaunchKernelGGL((k_extend<PRIMARY, false, false>), g.grid, g.block, 0, lc.stream, sc, cfg, pm, acc, wf);
+}
+
+void launchExtend(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
+                  const Wavefront& wf, bool primary) {
+  if (primary) dispatchExtend<true>(lc, sc, cfg, pm, acc, wf); else dispatchExtend<false>(lc, sc, cfg, pm, acc, wf);
 }
 
 void launchConnect(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, float area) {
@@ -729,10 +754,10 @@ void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, 
 }
 
 void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
-                 const Wavefront& wf, bool primary, int qIn, int qOut) {
+                 const Wavefront& wf, bool primary) {
   int numKinds = (cfg.hasLights ? (int)sc.numLightGroups : 0) + (cfg.hasSky ? 2 : 0);
-  if (primary) hipLaunchKernelGGL(k_shade<true>, dim3(PT_SEGS), dim3(256), 0, lc.stream, sc, cfg, pm, acc, wf, qIn, qOut, numKinds);
-  else hipLaunchKernelGGL(k_shade<false>, dim3(PT_SEGS), dim3(256), 0, lc.stream, sc, cfg, pm, acc, wf, qIn, qOut, numKinds);
+  if (primary) hipLaunchKernelGGL(k_shade<true>, dim3(PT_SEGS), dim3(256), 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+  else hipLaunchKernelGGL(k_shade<false>, dim3(PT_SEGS), dim3(256), 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
 }
 
 void launchAccumulate(const LaunchCfg& lc, const DevCfg& cfg, const PixMap& pm, float4* acc, const Wavefront& wf) {
