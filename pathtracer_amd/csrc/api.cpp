@@ -259,7 +259,8 @@ void ensureWavefront(PtHandle* h) {
   if (w.capSlots == capSlots && w.capQueue == (uint32_t)capQueue && w.lanes == lanes && h->wfKinds == kinds && h->wfRounds == rounds) return;
   HIPCHECK(hipStreamSynchronize(h->stream));
   h->bSlotQ.alloc((uint64_t)capSlots * 16);
-  h->bHitA.alloc(capQueue * 16); h->bHitB.alloc(capQueue * 16);
+  uint64_t capHit = capQueue + (uint64_t)PT_SEGS * PT_HIT_SLACK;
+  h->bHitA.alloc(capHit * 16); h->bHitB.alloc(capHit * 16);
   h->bRayO.alloc(NI ? capQueue * 16 : 16); h->bRayD.alloc(NI ? capQueue * 16 : 16);      // indirect rays only
   h->bLacc.alloc((uint64_t)lanes * capSlots * 16);
   h->bThr.alloc(NI ? (uint64_t)lanes * capSlots * 16 : 16);
@@ -286,7 +287,7 @@ void ensureWavefront(PtHandle* h) {
   w.Lacc = h->bLacc.as<float4>(); w.thr = h->bThr.as<float4>(); w.rng = h->bRng.as<uint2>();
   w.shO = h->bShO.as<float4>(); w.shD = h->bShD.as<float4>(); w.shW = h->bShW.as<float4>();
   w.stats = h->bStats.as<unsigned long long>();
-  w.capSlots = capSlots; w.capQueue = (uint32_t)capQueue; w.lanes = lanes;
+  w.capSlots = capSlots; w.capQueue = (uint32_t)capQueue; w.capHit = (uint32_t)capHit; w.lanes = lanes;
   h->wfKinds = kinds; h->wfRounds = rounds;
 }
 

@@ -95,7 +95,15 @@ struct QMeta {
   uint32_t* start;            // [PT_SEGS]      segment that holds flat entry T*P: where consumer block-task T starts
 };
 constexpr uint32_t PT_QMETA_WORDS = 3 * PT_SEGS + 2;
-constexpr int PT_TASK_COUNTERS = 16;   // one dynamic block-task counter per traversal launch of a stage
+constexpr int PT_TASK_COUNTERS = 16;   // one dynamic work counter per traversal launch of a stage
+
+// Traversal kernels consume a queue dynamically: a workgroup takes PT_SUPER consecutive flat entries from the
+// launch's global counter into an LDS pool, and its waves take 64 at a time from the pool, independently of
+// each other (no barrier between chunks: a wave with long traversals does not hold the others back).  Extend,
+// the one traversal kernel with an output queue, gives each workgroup a run of adjacent segments to append to;
+// PT_HIT_SLACK extra entries per segment guarantee that the workgroups that still have room can take all input.
+constexpr uint32_t PT_SUPER = 2048;
+constexpr uint32_t PT_HIT_SLACK = PT_SUPER + 1024;
 
 struct Wavefront {
   float4* slotQ;              // view rays that may hit something: (dir.xyz, path slot); the origin is the camera
@@ -116,7 +124,8 @@ struct Wavefront {
   uint32_t* taskCounters;     // [PT_TASK_COUNTERS], zeroed by the scan that precedes the launches using them
   unsigned long long* stats;  // see STAT_*
   uint32_t capSlots;          // primary slots per batch (multiple of 64 * PT_SEGS)
-  uint32_t capQueue;          // entries per queue (capSlots * max(1, numIndirect) in mode 1)
+  uint32_t capQueue;          // entries per ray / shadow queue (capSlots * max(1, numIndirect) in mode 1)
+  uint32_t capHit;            // entries of the hit queue: capQueue + PT_SEGS * PT_HIT_SLACK
   uint32_t lanes;             // 1 + numIndirect in mode 1, else 1
 };
 

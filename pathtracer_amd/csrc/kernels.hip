@@ -214,14 +214,65 @@ __global__ void __launch_bounds__(1024) k_scan(const QMeta* __restrict__ metas, 
   q.start[tid] = s;
 }
 
-// Dynamic block-task distribution for the persistent traversal kernels (PT_SEGS atomics per launch).
-// sTask[0] = task, sTask[1] = the workgroup's append counter for the task (reset here, between the barriers).
-__device__ __forceinline__ bool nextTask(uint32_t* counter, uint32_t* sTask, uint32_t& T) {
-  __syncthreads();
-  if (threadIdx.x == 0) { sTask[0] = atomicAdd(counter, 1u); sTask[1] = 0; }
-  __syncthreads();
-  T = sTask[0];
-  return T < PT_SEGS;
+// Physical index of flat entry j, starting the search at any segment (a hint that may be off in either direction).
+__device__ __forceinline__ uint32_t physIndexHint(const QMeta& q, uint32_t j, uint32_t seg, uint32_t segCap) {
+  uint32_t lo = q.prefix[seg];
+  while (j < lo) { seg--; lo = q.prefix[seg]; }
+  uint32_t hi = q.prefix[seg + 1];
+  while (j >= hi) { seg++; lo = hi; hi = q.prefix[seg + 1]; }
+  return seg * segCap + (j - lo);
+}
+
+// Dynamic distribution of a flat queue over the waves of the persistent traversal kernels.  The launch's global
+// counter hands out PT_SUPER consecutive entries at a time to a workgroup (total / PT_SUPER atomics per launch);
+// the workgroup's waves take 64 at a time from the LDS pool: state = (end << 32) | next, advanced by a 64-bit
+// compare-and-swap.  Only the wave that holds `lock` refills, and only an empty pool is ever refilled, so a
+// successful compare-and-swap always advanced the range it read.  Waves never wait for each other between chunks.
+struct WorkPool { unsigned long long state; uint32_t lock, done, seg, out; };
+struct Chunk { uint32_t begin, end, seg; };
+
+__device__ __forceinline__ void initPool(WorkPool* p) {
+  if (threadIdx.x == 0) { p->state = 0; p->lock = 0; p->done = 0; p->seg = 0; p->out = 0; }
+}
+
+// Next chunk for the calling wave (wave-uniform result); false when the queue is drained.  outLimit != 0: the
+// workgroup appends at most one entry per input entry to a region of outLimit entries counted in p->out, and stops
+// taking input when the entries already taken plus a new refill could overflow the region.
+__device__ __forceinline__ bool nextChunk(WorkPool* p, uint32_t* counter, const QMeta& q, uint32_t total, uint32_t outLimit, Chunk& c) {
+  uint32_t b = 0xFFFFFFFFu, e = 0, s = 0;
+  if ((threadIdx.x & 63) == 0) {
+    volatile WorkPool* vp = p;
+    for (;;) {
+      unsigned long long st = vp->state;
+      uint32_t next = (uint32_t)st, end = (uint32_t)(st >> 32);
+      if (next < end) {
+        if (atomicCAS(&p->state, st, st + 64) == st) { b = next; e = min(next + 64u, end); s = vp->seg; break; }
+        continue;
+      }
+      if (vp->done) break;
+      if (atomicCAS(&p->lock, 0u, 1u) == 0u) {
+        st = vp->state;
+        if ((uint32_t)st >= (uint32_t)(st >> 32) && !vp->done) {
+          bool full = outLimit && vp->out + blockDim.x + PT_SUPER > outLimit;   // + blockDim.x: chunks in flight
+          uint32_t g = full ? 0xFFFFFFFFu : atomicAdd(counter, PT_SUPER);
+          if (g >= total) vp->done = 1;
+          else {
+            vp->seg = q.start[g / q.prefix[PT_SEGS + 1]];
+            __threadfence_block();
+            atomicExch(&p->state, ((unsigned long long)min(g + PT_SUPER, total) << 32) | g);
+          }
+        }
+        __threadfence_block();
+        atomicExch(&p->lock, 0u);
+      } else {
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+  }
+  c.begin = __builtin_amdgcn_readfirstlane(b);
+  c.end = __builtin_amdgcn_readfirstlane(e);
+  c.seg = __builtin_amdgcn_readfirstlane(s);
+  return c.begin != 0xFFFFFFFFu;
 }
 
 // (pixel, sample index, view ray) of path slot i: getViewRay, rendering.d:278-285
@@ -289,44 +340,52 @@ __global__ void __launch_bounds__(256) k_raygen(CullBoxes cull, DevCfg cfg, PixM
 // (Ray.get(rayPos), rendering.d:390,472) so that shading never needs the ray again.
 template <bool PRIMARY, bool LDSS, bool COUNT>
 __global__ void __launch_bounds__(1024) k_extend(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, Wavefront wf) {
-  __shared__ __align__(16) uint32_t sTask[4];
+  __shared__ __align__(16) WorkPool pool;
+  initPool(&pool);
   stageScene<LDSS>(sc);
-  uint32_t cN = 0, cT = 0, T;
+  __syncthreads();
+  uint32_t cN = 0, cT = 0;
   const QMeta q = wf.rayIn;
-  const uint32_t segCapIn = (PRIMARY ? wf.capSlots : wf.capQueue) / PT_SEGS, segCapOut = wf.capQueue / PT_SEGS;
-  if (!PRIMARY && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&wf.stats[STAT_RAYS_INDIRECT], (unsigned long long)q.prefix[PT_SEGS]);
-  while (nextTask(wf.taskCounters, sTask, T)) {
-    Task tk = taskOf(q, T);
-    uint32_t seg = tk.seg;
-    for (uint32_t base = tk.begin; base < tk.end; base += blockDim.x) {
-      uint32_t j = base + threadIdx.x;
-      bool isHit = false;
-      V3 hitPos = v3(0, 0, 0); Hit h; h.t = 0; h.u = 0; h.v = 0; h.tri = 0; uint32_t slot = 0;
-      if (j < tk.end) {
-        uint32_t e = physIndex(q, j, seg, segCapIn);
-        V3 o, d;
-        if (PRIMARY) {
-          float4 sd = wf.slotQ[e];
-          o = cfg.cam.pos; d = xyz(sd); slot = f2u(sd.w);
-        } else {
-          float4 ro = wf.rayO[e], rd = wf.rayD[e];
-          o = xyz(ro); d = xyz(rd); slot = f2u(ro.w);
-        }
-        isHit = traverse<false, LDSS, COUNT>(sc, o, d, cfg.eps, h, cN, cT);
-        if (isHit) hitPos = o + d * h.t;
-        else if (PRIMARY) wf.Lacc[slot] = f4(sampleSky(d), 0.0f);
+  const uint32_t total = q.prefix[PT_SEGS];
+  const uint32_t segCapIn = (PRIMARY ? wf.capSlots : wf.capQueue) / PT_SEGS, segCapOut = wf.capHit / PT_SEGS;
+  // this workgroup appends to the adjacent output segments [segFirst, segLast): one contiguous region
+  const uint32_t segFirst = (uint32_t)(((uint64_t)blockIdx.x * PT_SEGS) / gridDim.x);
+  const uint32_t segLast = (uint32_t)(((uint64_t)(blockIdx.x + 1) * PT_SEGS) / gridDim.x);
+  const uint32_t outBase = segFirst * segCapOut, outLimit = (segLast - segFirst) * segCapOut;
+  if (!PRIMARY && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&wf.stats[STAT_RAYS_INDIRECT], (unsigned long long)total);
+  Chunk ck;
+  while (nextChunk(&pool, wf.taskCounters, q, total, outLimit, ck)) {
+    uint32_t j = ck.begin + (threadIdx.x & 63u);
+    bool isHit = false;
+    V3 hitPos = v3(0, 0, 0); Hit h; h.t = 0; h.u = 0; h.v = 0; h.tri = 0; uint32_t slot = 0;
+    if (j < ck.end) {
+      uint32_t e = physIndexHint(q, j, ck.seg, segCapIn);
+      V3 o, d;
+      if (PRIMARY) {
+        float4 sd = wf.slotQ[e];
+        o = cfg.cam.pos; d = xyz(sd); slot = f2u(sd.w);
+      } else {
+        float4 ro = wf.rayO[e], rd = wf.rayD[e];
+        o = xyz(ro); d = xyz(rd); slot = f2u(ro.w);
       }
-      uint32_t idx = waveAppend(isHit, &sTask[1]);
-      if (isHit) {
-        uint32_t e = T * segCapOut + idx;
-        wf.hitA[e] = f4(hitPos, u2f(h.tri));
-        wf.hitB[e] = make_float4(h.u, h.v, u2f(slot), h.t);
-      }
+      isHit = traverse<false, LDSS, COUNT>(sc, o, d, cfg.eps, h, cN, cT);
+      if (isHit) hitPos = o + d * h.t;
+      else if (PRIMARY) wf.Lacc[slot] = f4(sampleSky(d), 0.0f);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) wf.hitQ.count[T] = sTask[1];
+    uint32_t idx = waveAppend(isHit, &pool.out);
+    if (isHit) {
+      uint32_t e = outBase + idx;
+      wf.hitA[e] = f4(hitPos, u2f(h.tri));
+      wf.hitB[e] = make_float4(h.u, h.v, u2f(slot), h.t);
+    }
   }
   flushCounts<COUNT>(wf.stats, STAT_NODES_CLOSEST, cN, cT);
+  __syncthreads();
+  uint32_t n = pool.out;
+  for (uint32_t s = segFirst + threadIdx.x; s < segLast; s += blockDim.x) {
+    uint32_t before = (s - segFirst) * segCapOut;
+    wf.hitQ.count[s] = n > before ? min(n - before, segCapOut) : 0u;
+  }
 }
 
 // View rays generated in registers, no cull, no queue: the parity probe (getViewRay without jitter + Scene.trace).
@@ -354,15 +413,18 @@ __global__ void __launch_bounds__(1024) k_connect(DevScene sc, float eps, QMeta 
                                                   const float4* __restrict__ shD, const float4* __restrict__ shW,
                                                   uint32_t* taskCounter, float area, float4* __restrict__ Lacc,
                                                   unsigned long long* stats) {
-  __shared__ __align__(16) uint32_t sTask[4];
+  __shared__ __align__(16) WorkPool pool;
+  initPool(&pool);
   stageScene<LDSS>(sc);
-  uint32_t cN = 0, cT = 0, T;
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[STAT_RAYS_LIGHT], (unsigned long long)q.prefix[PT_SEGS]);
-  while (nextTask(taskCounter, sTask, T)) {
-    Task tk = taskOf(q, T);
-    uint32_t seg = tk.seg;
-    for (uint32_t j = tk.begin + threadIdx.x; j < tk.end; j += blockDim.x) {
-      uint32_t e = physIndex(q, j, seg, segCap);
+  __syncthreads();
+  uint32_t cN = 0, cT = 0;
+  const uint32_t total = q.prefix[PT_SEGS];
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[STAT_RAYS_LIGHT], (unsigned long long)total);
+  Chunk ck;
+  while (nextChunk(&pool, taskCounter, q, total, 0, ck)) {
+    uint32_t j = ck.begin + (threadIdx.x & 63u);
+    if (j < ck.end) {
+      uint32_t e = physIndexHint(q, j, ck.seg, segCap);
       float4 ro = shO[e], rd = shD[e];
       V3 phi = xyz(rd);
       Hit h;
@@ -393,15 +455,18 @@ template <bool LDSS, bool COUNT>
 __global__ void __launch_bounds__(1024) k_occluded(DevScene sc, float eps, QMeta q, uint32_t segCap, const float4* __restrict__ shO,
                                                    const float4* __restrict__ shD, const float4* __restrict__ shW,
                                                    uint32_t* taskCounter, float4* __restrict__ Lacc, unsigned long long* stats) {
-  __shared__ __align__(16) uint32_t sTask[4];
+  __shared__ __align__(16) WorkPool pool;
+  initPool(&pool);
   stageScene<LDSS>(sc);
-  uint32_t cN = 0, cT = 0, T;
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[STAT_RAYS_OCCL], (unsigned long long)q.prefix[PT_SEGS]);
-  while (nextTask(taskCounter, sTask, T)) {
-    Task tk = taskOf(q, T);
-    uint32_t seg = tk.seg;
-    for (uint32_t j = tk.begin + threadIdx.x; j < tk.end; j += blockDim.x) {
-      uint32_t e = physIndex(q, j, seg, segCap);
+  __syncthreads();
+  uint32_t cN = 0, cT = 0;
+  const uint32_t total = q.prefix[PT_SEGS];
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[STAT_RAYS_OCCL], (unsigned long long)total);
+  Chunk ck;
+  while (nextChunk(&pool, taskCounter, q, total, 0, ck)) {
+    uint32_t j = ck.begin + (threadIdx.x & 63u);
+    if (j < ck.end) {
+      uint32_t e = physIndexHint(q, j, ck.seg, segCap);
       float4 ro = shO[e], rd = shD[e];
       Hit h;
       if (!traverse<true, LDSS, COUNT>(sc, xyz(ro), xyz(rd), eps, h, cN, cT)) {
@@ -537,7 +602,7 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, DevCfg cfg, PixMap p
     uint32_t laneSlot = 0, depth = 0, gp = 0, sampleIdx = 0;
     Rng g; g.s0 = 1; g.s1 = 0;
     if (active) {
-      uint32_t e = physIndex(wf.hitQ, j, seg, segCap);
+      uint32_t e = physIndex(wf.hitQ, j, seg, wf.capHit / PT_SEGS);
       float4 ha = wf.hitA[e], hb = wf.hitB[e];
       hitPos = xyz(ha); laneSlot = f2u(hb.z);
       uint32_t tri = f2u(ha.w);
@@ -677,7 +742,7 @@ struct Geo { dim3 grid, block; size_t lds; };
 Geo traversalGeo(const LaunchCfg& lc, const DevScene& sc, uint64_t maxItems) {
   Geo g; g.lds = sc.ldsBytes;
   uint32_t bs, perCU;
-  if (sc.ldsBytes == 0) { bs = 256; perCU = 8; }
+  if (sc.ldsBytes == 0) { bs = 512; perCU = 4; }
   else if (sc.ldsBytes <= 18 * 1024) { bs = 256; perCU = 8; }
   else if (sc.ldsBytes <= 38 * 1024) { bs = 512; perCU = 4; }
   else if (sc.ldsBytes <= 78 * 1024) { bs = 1024; perCU = 2; }
@@ -727,6 +792,7 @@ template <bool PRIMARY>
 static void dispatchExtend(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
                            const Wavefront& wf) {
   Geo g = traversalGeo(lc, sc, wf.capQueue);
+  g.grid.x = std::min<unsigned>(g.grid.x, PT_SEGS);      // every workgroup owns at least one output segment
   bool l_ = sc.ldsBytes != 0, c_ = lc.countVisits;
   if (l_ && c_) { allowLds(lc, (const void*)k_extend<PRIMARY, true, true>, g.lds); hipLaunchKernelGGL((k_extend<PRIMARY, true, true>), g.grid, g.block, g.lds, lc.stream, sc, cfg, pm, acc, wf); }
   else if (l_) { allowLds(lc, (const void*)k_extend<PRIMARY, true, false>, g.lds); hipLaunchKernelGGL((k_extend<PRIMARY, true, false>), g.grid, g.block, g.lds, lc.stream, sc, cfg, pm, acc, wf); }
