@@ -58,7 +58,7 @@ struct PtHandle {
   DevBuf accOwn; float4* acc = nullptr; uint64_t accBytes = 0;
   // wavefront buffers
   DevBuf bSlotQ, bHitA, bHitB, bRayO, bRayD, bLacc, bThr, bRng, bShO, bShD, bShW, bCounters, bStats;
-  CullBoxes cull{};
+  SceneBox box{};
   DevBuf bMetaDesc; std::vector<QMeta> metas;     // queue descriptors: device copy and host copy, stage-major
   Wavefront wf{}; uint32_t wfKinds = 0, wfRounds = 0;
   // statistics
@@ -206,30 +206,7 @@ void uploadScene(PtHandle* h) {
   d.lightArea = h->dLightArea.as<float>();
   d.numNodes = bvh.numNodes; d.numTris = NT; d.numOrigTris = T; d.rootRef = bvh.rootRef;
   d.numLightGroups = (uint32_t)lt.numGroups();
-  {  // a cut through the top of the tree: repeatedly replace the largest internal box by its two children
-    struct Item { uint32_t node; float area; };
-    std::vector<Item> cut;
-    auto area = [&](uint32_t n) { const float* b = &bvh.nodes[(size_t)n * 8];
-                                  float dx = b[4] - b[0], dy = b[5] - b[1], dz = b[6] - b[2]; return dx * dy + dy * dz + dz * dx; };
-    auto refOf = [&](uint32_t n) { uint32_t r; std::memcpy(&r, &bvh.nodes[(size_t)n * 8 + 3], 4); return r; };
-    cut.push_back(Item{0, area(0)});
-    while (cut.size() < (size_t)PT_CULL_BOXES - 1) {
-      int best = -1;
-      for (size_t i = 0; i < cut.size(); i++)
-        if ((refOf(cut[i].node) >> BVH_COUNT_SHIFT) == 0 && (best < 0 || cut[i].area > cut[best].area)) best = (int)i;
-      if (best < 0) break;
-      uint32_t pair = refOf(cut[best].node) & BVH_INDEX_MASK;
-      cut[best] = Item{2 * pair, area(2 * pair)};
-      cut.push_back(Item{2 * pair + 1, area(2 * pair + 1)});
-    }
-    // box 0 is the root (most rays are decided by it alone); the cut follows unless it is the root itself
-    if (cut.size() == 1) cut.clear();
-    h->cull.count = (uint32_t)cut.size() + 1;
-    for (size_t i = 0; i <= cut.size(); i++) {
-      const float* b = &bvh.nodes[(size_t)(i ? cut[i - 1].node : 0) * 8];
-      for (int k = 0; k < 3; k++) { h->cull.mn[i][k] = b[k]; h->cull.mx[i][k] = b[4 + k]; }
-    }
-  }
+  for (int k = 0; k < 3; k++) { h->box.mn[k] = bvh.nodes[k]; h->box.mx[k] = bvh.nodes[4 + k]; }   // node 0 = root
   size_t ldsNeed = ((size_t)2 * bvh.numNodes + (size_t)3 * NT) * 16;
   d.ldsBytes = (!(h->cfg.flags & PT_FLAG_NO_LDS_SCENE) && ldsNeed <= 156 * 1024) ? (uint32_t)ldsNeed : 0;
   h->haveScene = true;
@@ -331,7 +308,7 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm) 
   };
   uint32_t nslots = pm.npix * pm.k;
   wf.rayOut = h->metas[1];
-  { Timed t(h, PT_K_OTHER); launchRaygen(lc, h->cull, dc, pm, h->acc, nslots, wf); t.done(); }
+  { Timed t(h, PT_K_OTHER); launchRaygen(lc, h->box, dc, pm, h->acc, nslots, wf); t.done(); }
   scan(1, 1);
   stage(1, true);
   h->st.raysPrimary += nslots; h->st.samples += nslots;

@@ -48,6 +48,12 @@ template <bool LDSS> __device__ __forceinline__ float4 ldNode(const DevScene& sc
 template <bool LDSS> __device__ __forceinline__ float4 ldTri(const DevScene& sc, uint32_t i) {
   if constexpr (LDSS) return g_lds[2 * sc.numNodes + i]; else return sc.tris[i];
 }
+// Keeps the .w of rows read from LDS live, so that they are read as ds_read_b128: when .w is unused the compiler
+// shortens the read to ds_read_b96, which occupies the LDS for 8 cycles per wave where ds_read_b128 takes 4.
+// Placed after the last read of a group (the asm waits for its operands).
+template <bool LDSS> __device__ __forceinline__ void keepW(const float4& a, const float4& b) {
+  if constexpr (LDSS) asm volatile("" ::"v"(a.w), "v"(b.w));
+}
 
 template <bool LDSS> __device__ __forceinline__ void stageScene(const DevScene& sc) {
   if constexpr (LDSS) {
@@ -82,8 +88,72 @@ __device__ __forceinline__ bool slab(const RayInv& r, float mnx, float mny, floa
 
 struct Hit { float t, u, v; uint32_t tri; };
 
+// One triangle of a leaf: the two-sided Moeller-Trumbore test in the fixed evaluation order of pt_math.h.
+// ANY: returns true when the hit is accepted (Scene.hitsNothing stops there).  Otherwise updates the closest
+// front-face hit and returns false.
+template <bool ANY, bool LDSS>
+__device__ __forceinline__ bool testTriangle(const DevScene& sc, uint32_t row, V3 o, V3 d, float eps, Hit& h, bool& found) {
+  float4 t0 = ldTri<LDSS>(sc, row), tA = ldTri<LDSS>(sc, row + 1), tB = ldTri<LDSS>(sc, row + 2);
+  keepW<LDSS>(tA, tB); keepW<LDSS>(t0, t0);
+  V3 A = xyz(tA), B = xyz(tB);
+  V3 p = cross(d, B);
+  float det = dot(A, p);
+  if (!(fabsf(det) < eps)) {
+    float inv = 1.0f / det;
+    V3 s = o - xyz(t0);
+    float u = dot(s, p) * inv;
+    if (!(u < 0.0f || u > 1.0f)) {
+      V3 q = cross(s, A);
+      float v = dot(d, q) * inv;
+      if (!(v < 0.0f || u + v > 1.0f)) {
+        float t = dot(B, q) * inv;
+        uint32_t orig = f2u(t0.w);
+        if (ANY) {
+          if (t >= eps) { h.t = t; h.u = u; h.v = v; h.tri = orig; return true; }
+        } else {
+          // pos < rayPos && pos >= FloatEpsilon, then front face; equal t keeps the lower triangle id
+          if ((t < h.t || (t == h.t && orig < h.tri)) && t >= eps && det < 0.0f) {
+            h.t = t; h.u = u; h.v = v; h.tri = orig; found = true;
+          }
+        }
+      }
+    }
+  }
+  return false;
+}
+
+// One step down the tree: tests the two children of internal node `ref` and returns the next reference -- the
+// nearer child that is hit (the other one is pushed), else the top of the stack, else PT_NONE.  Selects instead
+// of a three-way branch: the exec-mask bookkeeping of nested branches cost as many scalar instructions as the
+// two box tests cost vector instructions.
+constexpr uint32_t PT_NONE = 0xFFFFFFFFu;
+template <bool LDSS>
+__device__ __forceinline__ uint32_t stepDown(const DevScene& sc, const RayInv& ri, float tmax, uint32_t ref, uint32_t* stack, int& sp) {
+  uint32_t b = ref * 4;
+  float4 a0 = ldNode<LDSS>(sc, b), a1 = ldNode<LDSS>(sc, b + 1);
+  float4 b0 = ldNode<LDSS>(sc, b + 2), b1 = ldNode<LDSS>(sc, b + 3);
+  keepW<LDSS>(a1, b1);
+  float tn0, tn1;
+  bool h0 = slab(ri, a0.x, a0.y, a0.z, a1.x, a1.y, a1.z, tmax, tn0);
+  bool h1 = slab(ri, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, tmax, tn1);
+  uint32_t r0 = f2u(a0.w), r1 = f2u(b0.w);
+  bool sw = h1 && (!h0 || tn1 < tn0);
+  uint32_t nearRef = sw ? r1 : r0, farRef = sw ? r0 : r1;
+  if (h0 && h1) stack[sp++] = farRef;
+  if (h0 || h1) return nearRef;
+  return sp ? stack[--sp] : PT_NONE;
+}
+__device__ __forceinline__ bool isLeaf(uint32_t ref) { return (ref >> BVH_COUNT_SHIFT) != 0 && ref != PT_NONE; }
+__device__ __forceinline__ bool isInternal(uint32_t ref) { return (ref >> BVH_COUNT_SHIFT) == 0; }
+
 // Closest front-face hit (ANY = false: Scene.trace, scene.d:691-740) or first hit of either face
 // (ANY = true: Scene.hitsNothing, scene.d:808-835).  Returns true if something was accepted.
+//
+// COUNT = true walks in the canonical order (a leaf is tested as soon as it is reached) and counts box and
+// triangle tests per ray.  COUNT = false postpones the first leaf a lane reaches and keeps descending until no
+// lane of the wave is still looking for its first leaf; then the wave tests leaves together.  Fewer lanes idle
+// while others are in the other phase; the extra boxes tested with a not yet shortened ray do not change the
+// result (the closest hit does not depend on the order in which leaves are visited).
 template <bool ANY, bool LDSS, bool COUNT>
 __device__ __forceinline__ bool traverse(const DevScene& sc, V3 o, V3 d, float eps, Hit& h, uint32_t& cN, uint32_t& cT) {
   RayInv ri = makeRayInv(o, d);
@@ -92,61 +162,36 @@ __device__ __forceinline__ bool traverse(const DevScene& sc, V3 o, V3 d, float e
   uint32_t stack[64];
   int sp = 0;
   uint32_t ref = sc.rootRef;
-  bool live = true;
-  while (live) {
-    while ((ref >> BVH_COUNT_SHIFT) == 0) {
-      uint32_t b = ref * 4;
-      float4 a0 = ldNode<LDSS>(sc, b), a1 = ldNode<LDSS>(sc, b + 1);
-      float4 b0 = ldNode<LDSS>(sc, b + 2), b1 = ldNode<LDSS>(sc, b + 3);
-      if (COUNT) cN += 2;
-      float tn0, tn1;
-      bool h0 = slab(ri, a0.x, a0.y, a0.z, a1.x, a1.y, a1.z, h.t, tn0);
-      bool h1 = slab(ri, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, h.t, tn1);
-      uint32_t r0 = f2u(a0.w), r1 = f2u(b0.w);
-      // near child first; selects instead of a three-way branch (the exec-mask bookkeeping of nested branches
-      // cost as many scalar instructions as the two box tests cost vector instructions)
-      bool sw = h1 && (!h0 || tn1 < tn0);
-      uint32_t nearRef = sw ? r1 : r0, farRef = sw ? r0 : r1;
-      if (h0 && h1) stack[sp++] = farRef;
-      if (h0 || h1) ref = nearRef;
-      else {
-        if (sp == 0) { live = false; break; }
-        ref = stack[--sp];
+  if constexpr (COUNT) {
+    for (;;) {
+      while (isInternal(ref)) { cN += 2; ref = stepDown<LDSS>(sc, ri, h.t, ref, stack, sp); }
+      if (ref == PT_NONE) break;
+      uint32_t cnt = ref >> BVH_COUNT_SHIFT, first = ref & BVH_INDEX_MASK;
+      for (uint32_t i = 0; i < cnt; i++) {
+        cT += 1;
+        if (testTriangle<ANY, LDSS>(sc, (first + i) * 3, o, d, eps, h, found)) return true;
       }
+      if (sp == 0) break;
+      ref = stack[--sp];
     }
-    if (!live) break;
-    uint32_t cnt = ref >> BVH_COUNT_SHIFT, first = ref & BVH_INDEX_MASK;
-    for (uint32_t i = 0; i < cnt; i++) {
-      uint32_t r = (first + i) * 3;
-      float4 t0 = ldTri<LDSS>(sc, r), tA = ldTri<LDSS>(sc, r + 1), tB = ldTri<LDSS>(sc, r + 2);
-      if (COUNT) cT += 1;
-      V3 A = xyz(tA), B = xyz(tB);
-      V3 p = cross(d, B);
-      float det = dot(A, p);
-      if (!(fabsf(det) < eps)) {
-        float inv = 1.0f / det;
-        V3 s = o - xyz(t0);
-        float u = dot(s, p) * inv;
-        if (!(u < 0.0f || u > 1.0f)) {
-          V3 q = cross(s, A);
-          float v = dot(d, q) * inv;
-          if (!(v < 0.0f || u + v > 1.0f)) {
-            float t = dot(B, q) * inv;
-            uint32_t orig = f2u(t0.w);
-            if (ANY) {
-              if (t >= eps) { h.t = t; h.u = u; h.v = v; h.tri = orig; return true; }
-            } else {
-              // pos < rayPos && pos >= FloatEpsilon, then front face; equal t keeps the lower triangle id
-              if ((t < h.t || (t == h.t && orig < h.tri)) && t >= eps && det < 0.0f) {
-                h.t = t; h.u = u; h.v = v; h.tri = orig; found = true;
-              }
-            }
-          }
-        }
+  } else {
+    uint32_t leaf = PT_NONE;
+    if (isLeaf(ref)) { leaf = ref; ref = PT_NONE; }                        // the root is a leaf
+    for (;;) {
+      while (isInternal(ref)) {
+        ref = stepDown<LDSS>(sc, ri, h.t, ref, stack, sp);
+        if (leaf == PT_NONE && isLeaf(ref)) { leaf = ref; ref = sp ? stack[--sp] : PT_NONE; }
+        if (!__any(leaf == PT_NONE && ref != PT_NONE)) break;
       }
+      while (leaf != PT_NONE) {
+        uint32_t cnt = leaf >> BVH_COUNT_SHIFT, first = leaf & BVH_INDEX_MASK;
+        for (uint32_t i = 0; i < cnt; i++)
+          if (testTriangle<ANY, LDSS>(sc, (first + i) * 3, o, d, eps, h, found)) return true;
+        leaf = PT_NONE;
+        if (isLeaf(ref)) { leaf = ref; ref = sp ? stack[--sp] : PT_NONE; }
+      }
+      if (ref == PT_NONE) break;
     }
-    if (sp == 0) break;
-    ref = stack[--sp];
   }
   return found;
 }
@@ -297,11 +342,11 @@ __device__ __forceinline__ PrimaryRay primaryRay(const DevCfg& cfg, const PixMap
 }
 
 // ------------------------------------------------------------------------------------------------ raygen
-// Block-task T = blockIdx.x covers slots [T*P, (T+1)*P).  A view ray that misses every box of the BVH's top cut
-// cannot hit anything: its sample is finished here (sampleSky).  The others are queued as (direction, slot), 16 B:
-// the origin is the camera position and everything else is a function of the slot.  The boxes are kernel
-// arguments, i.e. scalar registers: the test costs no memory traffic.
-__global__ void __launch_bounds__(256) k_raygen(CullBoxes cull, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, uint32_t nslots,
+// Block-task T = blockIdx.x covers slots [T*P, (T+1)*P).  A view ray that misses the scene's box cannot hit
+// anything: its sample is finished here (sampleSky).  The others are queued as (direction, slot), 16 B: the origin
+// is the camera position and everything else is a function of the slot.  The box is a kernel argument, i.e. scalar
+// registers: the test costs no memory traffic.
+__global__ void __launch_bounds__(256) k_raygen(SceneBox box, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, uint32_t nslots,
                                                 Wavefront wf) {
   __shared__ uint32_t sCnt;
   if (threadIdx.x == 0) sCnt = 0;
@@ -316,12 +361,7 @@ __global__ void __launch_bounds__(256) k_raygen(CullBoxes cull, DevCfg cfg, PixM
       d = primaryRay(cfg, pm, acc, i, true).d;
       RayInv ri = makeRayInv(cfg.cam.pos, d);
       float tn;
-      // box 0 is the whole scene; only rays that enter it are tested against the boxes of the cut
-      if (slab(ri, cull.mn[0][0], cull.mn[0][1], cull.mn[0][2], cull.mx[0][0], cull.mx[0][1], cull.mx[0][2], PT_FLT_MAX, tn)) {
-        enter = cull.count <= 1;
-        for (uint32_t b = 1; b < cull.count; b++)
-          enter = enter || slab(ri, cull.mn[b][0], cull.mn[b][1], cull.mn[b][2], cull.mx[b][0], cull.mx[b][1], cull.mx[b][2], PT_FLT_MAX, tn);
-      }
+      enter = slab(ri, box.mn[0], box.mn[1], box.mn[2], box.mx[0], box.mx[1], box.mx[2], PT_FLT_MAX, tn);
       if (!enter) { wf.Lacc[i] = f4(sampleSky(d), 0.0f); culled++; }          // rendering.d:480
     }
     uint32_t idx = waveAppend(enter, &sCnt);
@@ -773,9 +813,9 @@ void allowLds(const LaunchCfg& lc, const void* kernel, size_t bytes) {
     else hipLaunchKernelGGL((KERNEL<false, false>), g.grid, g.block, 0, lc.stream, __VA_ARGS__);          \
   } while (0)
 
-void launchRaygen(const LaunchCfg& lc, const CullBoxes& cull, const DevCfg& cfg, const PixMap& pm, const float4* acc,
+void launchRaygen(const LaunchCfg& lc, const SceneBox& box, const DevCfg& cfg, const PixMap& pm, const float4* acc,
                   uint32_t nslots, const Wavefront& wf) {
-  hipLaunchKernelGGL(k_raygen, dim3(PT_SEGS), dim3(256), 0, lc.stream, cull, cfg, pm, acc, nslots, wf);
+  hipLaunchKernelGGL(k_raygen, dim3(PT_SEGS), dim3(256), 0, lc.stream, box, cfg, pm, acc, nslots, wf);
 }
 
 void launchScan(const LaunchCfg& lc, const QMeta* metas, int n, uint32_t* taskCounters) {
