@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libptgpu.so')
+LIB_PATH = os.environ.get('PTGPU_LIBRARY') or os.path.join(_HERE, 'libptgpu.so')   # override: A/B runs of two builds
 
 PT_OK, PT_E_INVALID, PT_E_STATE, PT_E_DEVICE, PT_E_IO, PT_E_NOMEM = 0, -1, -2, -3, -4, -5
 PT_FLAG_COUNT_VISITS, PT_FLAG_NO_LDS_SCENE, PT_FLAG_TIME_KERNELS = 1, 2, 4
