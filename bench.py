@@ -141,8 +141,9 @@ def main():
         else:
             dom, dom_ms, dom_launch, dom_bytes = 'occluded (any hit)', any_ms, st.kernelLaunches[2], st.raysOcclusion * bytes_any
         achieved = dom_bytes / max(1, dom_launch) / (dom_ms / max(1, dom_launch) * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic, traffic_src = measured_traffic(args, dom)
         roofline = dict(bound='hbm', achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None, kernel=dom,
+                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src, kernel=dom,
                         launches=int(dom_launch), avg_launch_us=round(1e3 * dom_ms / max(1, dom_launch), 3),
                         algorithmic_bytes_per_launch=round(dom_bytes / max(1, dom_launch), 1),
                         bytes_per_ray=dict(closest=round(bytes_closest, 2), any=round(bytes_any, 2)),
@@ -175,6 +176,20 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(args, dom):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE need separate profiler runs, so they cannot be taken inside this process).  Only for the default
+    workload and batch size, which is what those passes ran; otherwise None."""
+    path = os.path.join(ROOT, 'profiles', 'r01_c2_hbm_traffic.json')
+    if args.workload != 'c2_teapot_1080p_256spp' or args.batch_slots or args.max_leaf or not os.path.exists(path):
+        return None, None
+    want = 'k_occluded<true, false>' if dom.startswith('occluded') else 'k_extend<true, true, false>'
+    k = json.load(open(path))['kernels'].get(want)
+    if not k:
+        return None, None
+    return k['hbm_bytes_per_launch'], 'profiles/r01_c2_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
 
 
 def cpu_baseline(wl, W, H, model, target_seconds):

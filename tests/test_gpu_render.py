@@ -126,6 +126,22 @@ def test_batching_progression_and_windows_do_not_change_the_image(require_gpu):
     assert np.array_equal(m1.read_pixels()['sum'].view(np.uint32), m2.read_pixels()['sum'].view(np.uint32))
 
 
+def test_full_batches_where_nearly_every_ray_hits(require_gpu, flats):
+    """Batches that fill the wavefront's capacity exactly (256x256 pixels = the 65536-slot minimum) in a scene where
+    almost every view ray hits: the hit queue receives as many entries as the ray queue held, which is the case the
+    per-workgroup output regions of extend are sized for.  Bit-identical to the oracle with the same streams."""
+    name, W, H, spp = 'cornell-box', 256, 256, 3
+    pt = make_tracer(name, W, H, seed=77, batch_slots=65536)
+    pt.render_frame(spp)
+    got = pt.read_pixels()
+    o = make_oracle(flats[name], name, W, H, has_sky=False, seed=77)
+    ref = oracle_py.new_pixels(W * H); o.render_keyed(ref, 0, spp, nthreads=8)
+    assert (got['n'] == spp).all()
+    assert np.array_equal(got['sum'].view(np.uint32), ref['sum'].view(np.uint32))
+    hit = pt.trace_primary()[0] >= 0
+    assert hit.mean() > 0.95
+
+
 def test_band_and_sample_splits_reassemble_bit_identically(require_gpu):
     """Two handles stand in for two GPUs: interleaved 4-scanline bands summed == one GPU; sample slices summed ==
     the per-slice images added."""
