@@ -27,6 +27,8 @@ WORKLOADS = {
     'c1_cornell_512_16spp': dict(model='cornell-box', W=512, H=512, spp=16, sky=0, mode=0, frm=(-1, 26.5, 10), to=(0, 0, 9)),
     'c3_chest1_1080p_1024spp': dict(model='chest1', W=1920, H=1080, spp=1024, sky=1, mode=1, frm=(3, 3, 3), to=(0, 0, 0)),
     'c4_cornell_4k_4096spp': dict(model='cornell-box', W=3840, H=2160, spp=4096, sky=0, mode=0, frm=(-1, 26.5, 10), to=(0, 0, 9)),
+    # synthetic soup (pathtracer_amd/synthetic.py), scene traversed from HBM; --soup-tris sets the size
+    'c5_soup_4k_1024spp': dict(model='soup', W=3840, H=2160, spp=1024, sky=1, mode=0, frm=(250, 180, 160), to=(0, 0, 0)),
 }
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak
 B_STREAM_CLOSEST, B_STREAM_ANY, B_NODE, B_TRI = 48.0, 36.0, 32.0, 36.0   # algorithmic bytes per ray / node / triangle
@@ -47,6 +49,7 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target CPU time of the cpu_baseline leg (0 = skip)')
     ap.add_argument('--batch-slots', type=int, default=0)
     ap.add_argument('--max-leaf', type=int, default=0)
+    ap.add_argument('--soup-tris', type=int, default=10_000_000, help='triangles of the synthetic soup workload')
     args = ap.parse_args()
 
     import numpy as np
@@ -75,7 +78,14 @@ def main():
                       batch_slots=args.batch_slots, max_leaf_tris=args.max_leaf)
     pt.set_stream(torch.cuda.current_stream().cuda_stream)
     pt.bind_accumulator(acc)
-    pt.Scene(model)
+    if wl['model'] == 'soup':
+        from pathtracer_amd.synthetic import soup
+        t_b = time.perf_counter()
+        pt.upload_scene(**soup(args.soup_tris))
+        print('soup: %d triangles, scene prepared (BVH build on the host) in %.1f s' % (args.soup_tris, time.perf_counter() - t_b),
+              file=sys.stderr, flush=True)
+    else:
+        pt.Scene(model)
     pt.set_camera(P.Camera(30.0, H / W).setTransform(wl['frm'], wl['to'], (0, 0, 1)))
 
     def step():
@@ -152,7 +162,7 @@ def main():
                              'HBM carries only the ray/hit/shadow-queue streams' if st.sceneInLds else 'scene traversed from HBM/L2')
 
         cpu = None
-        if world == 1 and args.cpu_seconds > 0:
+        if world == 1 and args.cpu_seconds > 0 and wl['model'] != 'soup':     # the oracle's O(T^2) tree build rules the soup out
             cpu = cpu_baseline(wl, W, H, model, args.cpu_seconds)
 
         out = {
@@ -160,7 +170,8 @@ def main():
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak' if args.split == 'samples' else 'strong', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic camera + the reference\'s shipped teapot.thModel geometry' if wl['model'] == 'teapot'
-            else 'reference-shipped %s.thModel geometry' % wl['model'],
+            else ('synthetic triangle soup (%d triangles)' % args.soup_tris if wl['model'] == 'soup'
+                  else 'reference-shipped %s.thModel geometry' % wl['model']),
             'config': {'workload': args.workload + ('' if not args.spp else ' (spp overridden to %d)' % spp),
                        'width': W, 'height': H, 'spp_per_gpu': spp, 'spp_total': spp * (world if args.split == 'samples' else 1),
                        'mode': wl['mode'], 'hasSky': wl['sky'], 'split': args.split, 'triangles': int(st.numTriangles),

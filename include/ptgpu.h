@@ -60,6 +60,8 @@ typedef struct PtConfig {
 #define PT_FLAG_COUNT_VISITS 1u   /* count BVH node boxes tested / triangles tested per ray kind (slow) */
 #define PT_FLAG_NO_LDS_SCENE 2u   /* keep nodes/triangles in global memory even if they fit in LDS     */
 #define PT_FLAG_TIME_KERNELS 4u   /* bracket every kernel launch with events (ptgpu_get_stats)         */
+#define PT_FLAG_NO_COVERAGE_MASK 8u /* cull view rays by the scene's bounding box only, not by the per-pixel
+                                       screen-space coverage mask of the triangles                       */
 
 typedef struct PtMaterial { float emissive; float color[3]; } PtMaterial;        /* rendering.d:33-37 */
 typedef struct PtPixel { float color[3]; float n; float sum[3]; } PtPixel;        /* rendering.d:24-30 */
@@ -75,7 +77,8 @@ typedef struct PtStats {
   uint64_t samples;          /* computeL invocations                                                     */
   uint64_t nodesClosest, trisClosest;   /* with PT_FLAG_COUNT_VISITS: box tests / triangle tests, closest-hit rays */
   uint64_t nodesAny, trisAny;           /* same for any-hit rays                                          */
-  uint64_t raysCulled;       /* view rays answered by the scene bounding box alone (included in raysPrimary) */
+  uint64_t raysCulled;       /* view rays answered without a traversal: pixel outside every triangle's screen
+                                rectangle, or ray outside the scene's bounding box (included in raysPrimary)  */
   double kernelMs[PT_K_COUNT];          /* with PT_FLAG_TIME_KERNELS: summed event time per kernel kind   */
   uint64_t kernelLaunches[PT_K_COUNT];
   double renderMs;           /* event time first kernel -> last kernel of all ptgpu_render calls          */
@@ -149,6 +152,11 @@ int ptgpu_trace_primary(PtHandle* h, uint32_t pixelOffset, uint32_t count, int32
 int ptgpu_view_rays(PtHandle* h, uint32_t pixelOffset, uint32_t count, float* rays6);
 /* First n words of RNG stream (seed, pixel, sample, stream) as the kernels draw them. */
 int ptgpu_rng_stream(PtHandle* h, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n, uint32_t* out);
+/* Parity probe (no reference counterpart): the coverage mask the view rays of getViewRay (rendering.d:278-285) are
+ * culled with for the current scene and camera -- bit p of bits (ceil(width*height/32) words) set when pixel p may see
+ * a triangle.  *usable = 0 when no mask can be built for this camera (a triangle reaches behind it); rendering then
+ * culls by the scene's bounding box.  Works on host-only handles. */
+int ptgpu_get_coverage_mask(PtHandle* h, uint32_t* bits, uint32_t* usable);
 
 int ptgpu_get_stats(PtHandle* h, PtStats* out);
 int ptgpu_reset_stats(PtHandle* h);

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PTGPU_LIBRARY') or os.path.join(_HERE, 'libptgpu.so')   # override: A/B runs of two builds
 
 PT_OK, PT_E_INVALID, PT_E_STATE, PT_E_DEVICE, PT_E_IO, PT_E_NOMEM = 0, -1, -2, -3, -4, -5
-PT_FLAG_COUNT_VISITS, PT_FLAG_NO_LDS_SCENE, PT_FLAG_TIME_KERNELS = 1, 2, 4
+PT_FLAG_COUNT_VISITS, PT_FLAG_NO_LDS_SCENE, PT_FLAG_TIME_KERNELS, PT_FLAG_NO_COVERAGE_MASK = 1, 2, 4, 8
 PT_K_NAMES = ('extend', 'connect', 'occluded', 'shade', 'accumulate', 'other')
 
 
@@ -55,6 +55,7 @@ SYMBOLS = {
     'ptgpu_trace_primary': (_I, [_VP, _U32, _U32, _VP, _VP, _VP, _VP]),
     'ptgpu_view_rays': (_I, [_VP, _U32, _U32, _VP]),
     'ptgpu_rng_stream': (_I, [_VP, _U32, _U32, _U32, _U32, _VP]),
+    'ptgpu_get_coverage_mask': (_I, [_VP, _VP, _VP]),
     'ptgpu_get_stats': (_I, [_VP, C.POINTER(PtStats)]),
     'ptgpu_reset_stats': (_I, [_VP]),
     'ptgpu_bind_accumulator': (_I, [_VP, _VP, C.c_uint64]),

@@ -234,6 +234,16 @@ class PathTracer:
         self._check(self.lib.ptgpu_rng_stream(self.h, pixel, sample, stream, n, _ptr(out)))
         return out
 
+    def coverage_mask(self):
+        """Boolean array (height*width): pixels whose view rays may hit a triangle; None when no mask can be built
+        for the current camera (rendering then culls by the scene's bounding box)."""
+        npix = self.width * self.height
+        bits = np.zeros((npix + 31) // 32, np.uint32); usable = np.zeros(1, np.uint32)
+        self._check(self.lib.ptgpu_get_coverage_mask(self.h, _ptr(bits), _ptr(usable)))
+        if not usable[0]:
+            return None
+        return np.unpackbits(bits.view(np.uint8), bitorder='little')[:npix].astype(bool)
+
     # ------------------------------------------------------------------ statistics
     def stats(self):
         st = PtStats()

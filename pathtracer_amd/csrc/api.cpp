@@ -59,6 +59,8 @@ struct PtHandle {
   // wavefront buffers
   DevBuf bSlotQ, bHitA, bHitB, bRayO, bRayD, bLacc, bThr, bRng, bShO, bShD, bShW, bCounters, bStats;
   SceneBox box{};
+  // coverage mask of the view rays (scene_host.h: buildCoverageMask); rebuilt when the scene or the camera changes
+  DevBuf dMask; bool maskDirty = true, maskUsable = false;
   DevBuf bMetaDesc; std::vector<QMeta> metas;     // queue descriptors: device copy and host copy, stage-major
   Wavefront wf{}; uint32_t wfKinds = 0, wfRounds = 0;
   // statistics
@@ -184,6 +186,7 @@ void uploadScene(PtHandle* h) {
 
   h->st.numTriangles = T; h->st.numNodes = bvh.numNodes; h->st.bvhDepth = bvh.depth;
   h->st.numLightGroups = (uint32_t)lt.numGroups();
+  h->maskDirty = true;
   if (h->cfg.device < 0) { h->haveScene = true; return; }
   auto up = [&](DevBuf& b, const void* src, size_t bytes) {
     b.alloc(bytes);
@@ -308,7 +311,7 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm) 
   };
   uint32_t nslots = pm.npix * pm.k;
   wf.rayOut = h->metas[1];
-  { Timed t(h, PT_K_OTHER); launchRaygen(lc, h->box, dc, pm, h->acc, nslots, wf); t.done(); }
+  { Timed t(h, PT_K_OTHER); launchRaygen(lc, h->box, h->maskUsable ? h->dMask.as<uint32_t>() : nullptr, dc, pm, h->acc, nslots, wf); t.done(); }
   scan(1, 1);
   stage(1, true);
   h->st.raysPrimary += nslots; h->st.samples += nslots;
@@ -336,6 +339,16 @@ void renderPixels(PtHandle* h, PixMap base, uint64_t totalPix, uint32_t spp) {
   if (!h->haveCamera) fail(PT_E_STATE, "no camera: call ptgpu_set_camera or ptgpu_camera_look_at first");
   if (totalPix == 0 || spp == 0) return;
   ensureWavefront(h);
+  if (h->maskDirty) {
+    std::vector<uint32_t> bits;
+    h->maskUsable = !(h->cfg.flags & PT_FLAG_NO_COVERAGE_MASK) && buildCoverageMask(h->flat, h->cam, h->cfg.width, h->cfg.height, bits);
+    if (h->maskUsable) {
+      HIPCHECK(hipStreamSynchronize(h->stream));
+      h->dMask.alloc(bits.size() * 4);
+      HIPCHECK(hipMemcpy(h->dMask.p, bits.data(), bits.size() * 4, hipMemcpyHostToDevice));
+    }
+    h->maskDirty = false;
+  }
   DevCfg dc = makeDevCfg(h); LaunchCfg lc = makeLaunchCfg(h);
   Timed span(h, KIND_RENDER, true);
   uint32_t W = h->cfg.width;
@@ -421,6 +434,7 @@ int ptgpu_set_config(PtHandle* h, const PtConfig* cfg) {
     if (c.device != h->cfg.device || c.width != h->cfg.width || c.height != h->cfg.height || c.batchSlots != h->cfg.batchSlots)
       fail(PT_E_INVALID, "device, width, height and batchSlots are fixed at ptgpu_create");
     bool rebuild = c.maxLeafTris != h->cfg.maxLeafTris || ((c.flags ^ h->cfg.flags) & PT_FLAG_NO_LDS_SCENE);
+    if ((c.flags ^ h->cfg.flags) & PT_FLAG_NO_COVERAGE_MASK) h->maskDirty = true;
     h->cfg = c;
     if (rebuild && h->haveScene) { if (h->cfg.device >= 0) useDevice(h); uploadScene(h); }
   });
@@ -493,7 +507,7 @@ int ptgpu_set_camera(PtHandle* h, const float pos[3], const float dir[3], const 
     if (!h || !pos || !dir || !right || !up) fail(PT_E_INVALID, "null argument");
     h->cam.pos = v3(pos[0], pos[1], pos[2]); h->cam.dir = v3(dir[0], dir[1], dir[2]);
     h->cam.right = v3(right[0], right[1], right[2]); h->cam.up = v3(up[0], up[1], up[2]);
-    h->cam.tanFov = tanFov; h->cam.aspect = aspect; h->haveCamera = true;
+    h->cam.tanFov = tanFov; h->cam.aspect = aspect; h->haveCamera = true; h->maskDirty = true;
   });
 }
 
@@ -502,7 +516,7 @@ int ptgpu_camera_look_at(PtHandle* h, float fovDegrees, float aspect, const floa
   return guarded([&]() {
     if (!from || !to || !up) fail(PT_E_INVALID, "null argument");
     Camera c = cameraLookAt(fovDegrees, aspect, v3(from[0], from[1], from[2]), v3(to[0], to[1], to[2]), v3(up[0], up[1], up[2]));
-    if (h) { h->cam = c; h->haveCamera = true; }
+    if (h) { h->cam = c; h->haveCamera = true; h->maskDirty = true; }
     if (out14) {
       float r[14] = {c.pos.x, c.pos.y, c.pos.z, c.dir.x, c.dir.y, c.dir.z, c.right.x, c.right.y, c.right.z,
                      c.up.x, c.up.y, c.up.z, c.tanFov, c.aspect};
@@ -662,6 +676,18 @@ int ptgpu_view_rays(PtHandle* h, uint32_t off, uint32_t count, float* rays6) {
     launchViewRays(makeLaunchCfg(h), makeDevCfg(h), off, count, d.as<float>());
     HIPCHECK(hipMemcpyAsync(rays6, d.p, (size_t)count * 24, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
+  });
+}
+
+int ptgpu_get_coverage_mask(PtHandle* h, uint32_t* bits, uint32_t* usable) {
+  return guarded([&]() {
+    if (!h || !usable) fail(PT_E_INVALID, "null argument");
+    if (!h->haveScene) fail(PT_E_STATE, "no scene");
+    if (!h->haveCamera) fail(PT_E_STATE, "no camera");
+    std::vector<uint32_t> m;
+    bool ok = buildCoverageMask(h->flat, h->cam, h->cfg.width, h->cfg.height, m);
+    *usable = ok ? 1u : 0u;
+    if (ok && bits) std::memcpy(bits, m.data(), m.size() * 4);
   });
 }
 

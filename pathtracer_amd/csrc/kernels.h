@@ -101,7 +101,11 @@ constexpr int PT_TASK_COUNTERS = 16;   // one dynamic work counter per traversal
 // launch's global counter into an LDS pool, and its waves take 64 at a time from the pool, independently of
 // each other (no barrier between chunks: a wave with long traversals does not hold the others back).  Extend,
 // the one traversal kernel with an output queue, gives each workgroup a run of adjacent segments to append to;
-// PT_HIT_SLACK extra entries per segment guarantee that the workgroups that still have room can take all input.
+// PT_HIT_SLACK extra entries per segment guarantee that the workgroups that still have room can take all input:
+// a workgroup stops taking input only when its region could not hold one more refill plus the chunks in flight
+// (out + blockDim + PT_SUPER > region), i.e. when out > region - PT_HIT_SLACK >= its share of capQueue.  If every
+// workgroup had stopped, the outputs would sum to more than capQueue, but there are never more outputs than input
+// entries and the input queue holds at most capQueue.
 constexpr uint32_t PT_SUPER = 2048;
 constexpr uint32_t PT_HIT_SLACK = PT_SUPER + 1024;
 
@@ -135,8 +139,9 @@ enum { STAT_RAYS_LIGHT = 0, STAT_RAYS_INDIRECT, STAT_RAYS_OCCL, STAT_NODES_CLOSE
 struct LaunchCfg { int device; int numCUs; bool countVisits; hipStream_t stream; };
 
 // ---- wavefront stages (all asynchronous on lc.stream) ----
-void launchRaygen(const LaunchCfg& lc, const SceneBox& box, const DevCfg& cfg, const PixMap& pm, const float4* acc,
-                  uint32_t nslots, const Wavefront& wf);
+// mask: one bit per frame pixel (scene_host.h: buildCoverageMask), or null to cull by the scene box
+void launchRaygen(const LaunchCfg& lc, const SceneBox& box, const uint32_t* mask, const DevCfg& cfg, const PixMap& pm,
+                  const float4* acc, uint32_t nslots, const Wavefront& wf);
 // prefix sums + consumer start segments for n queues, and zeroing of the stage's dynamic task counters
 void launchScan(const LaunchCfg& lc, const QMeta* metas, int n, uint32_t* taskCounters);
 // primary: entries of wf.rayIn index wf.slotQ (view direction + path slot); else wf.rayO / wf.rayD

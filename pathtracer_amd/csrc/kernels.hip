@@ -393,8 +393,11 @@ __device__ __forceinline__ PrimaryRay primaryRay(const DevCfg& cfg, const PixMap
 // anything: its sample is finished here (sampleSky).  The others are queued as (direction, slot), 16 B: the origin
 // is the camera position and everything else is a function of the slot.  The box is a kernel argument, i.e. scalar
 // registers: the test costs no memory traffic.
-__global__ void __launch_bounds__(256) k_raygen(SceneBox box, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, uint32_t nslots,
-                                                Wavefront wf) {
+// With a coverage mask (one bit per pixel: some triangle's screen rectangle, grown by the sample jitter, overlaps
+// the pixel) the bit decides instead of the box: for an object in front of a background it culls nearly every ray
+// that would traverse the tree and come back empty.
+__global__ void __launch_bounds__(256) k_raygen(SceneBox box, const uint32_t* __restrict__ mask, DevCfg cfg, PixMap pm,
+                                                const float4* __restrict__ acc, uint32_t nslots, Wavefront wf) {
   __shared__ uint32_t sCnt;
   if (threadIdx.x == 0) sCnt = 0;
   __syncthreads();
@@ -405,10 +408,14 @@ __global__ void __launch_bounds__(256) k_raygen(SceneBox box, DevCfg cfg, PixMap
     bool enter = false;
     V3 d = v3(0, 0, 0);
     if (i < end) {
-      d = primaryRay(cfg, pm, acc, i, true).d;
-      RayInv ri = makeRayInv(cfg.cam.pos, d);
-      float tn;
-      enter = slab(ri, box.mn[0], box.mn[1], box.mn[2], box.mx[0], box.mx[1], box.mx[2], PT_FLT_MAX, tn);
+      PrimaryRay pr = primaryRay(cfg, pm, acc, i, true);
+      d = pr.d;
+      if (mask) enter = (mask[pr.gp >> 5] >> (pr.gp & 31u)) & 1u;
+      else {
+        RayInv ri = makeRayInv(cfg.cam.pos, d);
+        float tn;
+        enter = slab(ri, box.mn[0], box.mn[1], box.mn[2], box.mx[0], box.mx[1], box.mx[2], PT_FLT_MAX, tn);
+      }
       if (!enter) { wf.Lacc[i] = f4(sampleSky(d), 0.0f); culled++; }          // rendering.d:480
     }
     uint32_t idx = waveAppend(enter, &sCnt);
@@ -860,9 +867,9 @@ void allowLds(const LaunchCfg& lc, const void* kernel, size_t bytes) {
     else hipLaunchKernelGGL((KERNEL<false, false>), g.grid, g.block, 0, lc.stream, __VA_ARGS__);          \
   } while (0)
 
-void launchRaygen(const LaunchCfg& lc, const SceneBox& box, const DevCfg& cfg, const PixMap& pm, const float4* acc,
-                  uint32_t nslots, const Wavefront& wf) {
-  hipLaunchKernelGGL(k_raygen, dim3(PT_SEGS), dim3(256), 0, lc.stream, box, cfg, pm, acc, nslots, wf);
+void launchRaygen(const LaunchCfg& lc, const SceneBox& box, const uint32_t* mask, const DevCfg& cfg, const PixMap& pm,
+                  const float4* acc, uint32_t nslots, const Wavefront& wf) {
+  hipLaunchKernelGGL(k_raygen, dim3(PT_SEGS), dim3(256), 0, lc.stream, box, mask, cfg, pm, acc, nslots, wf);
 }
 
 void launchScan(const LaunchCfg& lc, const QMeta* metas, int n, uint32_t* taskCounters) {

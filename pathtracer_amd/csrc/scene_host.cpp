@@ -160,4 +160,72 @@ Camera cameraLookAt(float fovDegrees, float aspect, V3 from, V3 to, V3 up) {
   return c;
 }
 
+bool buildCoverageMask(const FlatScene& scene, const Camera& cam, uint32_t W, uint32_t H, std::vector<uint32_t>& bits) {
+  // A view ray through screen position (x, y) has direction dir + right*(x*tanFov) + up*(y*tanFov*aspect)
+  // (camera.d:38-42).  Point p (relative to the camera) lies on it iff p = t*(dir + a*right + b*up) with t > 0,
+  // x = a/tanFov, y = b/(tanFov*aspect): solve with the inverse of the matrix whose columns are dir, right, up.
+  const double m[3][3] = {{cam.dir.x, cam.right.x, cam.up.x}, {cam.dir.y, cam.right.y, cam.up.y}, {cam.dir.z, cam.right.z, cam.up.z}};
+  double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+               m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+  double sx = (double)cam.tanFov, sy = (double)cam.tanFov * (double)cam.aspect;
+  if (!(std::fabs(det) > 1e-12) || !(std::fabs(sx) > 1e-12) || !(std::fabs(sy) > 1e-12)) return false;
+  double inv[3][3];
+  inv[0][0] = (m[1][1] * m[2][2] - m[1][2] * m[2][1]) / det; inv[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) / det;
+  inv[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) / det; inv[1][0] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) / det;
+  inv[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) / det; inv[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) / det;
+  inv[2][0] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) / det; inv[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) / det;
+  inv[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) / det;
+
+  // scene scale: a vertex closer to the camera plane than this is treated as "not in front"
+  double scale = 1e-30;
+  for (float f : scene.v) if (std::isfinite(f)) scale = std::max(scale, (double)std::fabs(f));
+  scale = std::max({scale, (double)std::fabs(cam.pos.x), (double)std::fabs(cam.pos.y), (double)std::fabs(cam.pos.z)});
+  const double tMin = 1e-6 * scale;
+
+  const size_t wordsPerRow = ((size_t)W + 31) / 32;           // rows are padded to whole words while marking
+  std::vector<uint32_t> rows((size_t)H * wordsPerRow, 0u);
+  // sample positions of pixel (col, row): x in col*2/W - 1 + [-1/W, 1/W), i.e. within half a pixel of the pixel's
+  // nominal position; margin: 0.05 pixel for the fp32 rounding of the device's ray set-up and triangle test
+  const double margin = 0.55;
+  size_t T = scene.numTriangles();
+  for (size_t i = 0; i < T; i++) {
+    const float* p = &scene.v[9 * i];
+    bool finite = true;
+    for (int k = 0; k < 9; k++) finite = finite && std::isfinite(p[k]);
+    if (!finite) continue;                                    // never hit (no BVH leaf holds it)
+    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+    for (int v = 0; v < 3; v++) {
+      double q[3] = {(double)p[3 * v] - cam.pos.x, (double)p[3 * v + 1] - cam.pos.y, (double)p[3 * v + 2] - cam.pos.z};
+      double t = inv[0][0] * q[0] + inv[0][1] * q[1] + inv[0][2] * q[2];
+      double a = inv[1][0] * q[0] + inv[1][1] * q[1] + inv[1][2] * q[2];
+      double b = inv[2][0] * q[0] + inv[2][1] * q[1] + inv[2][2] * q[2];
+      if (!(t > tMin)) return false;
+      double px = (a / (t * sx) + 1.0) * 0.5 * (double)W, py = (b / (t * sy) + 1.0) * 0.5 * (double)H;   // in pixels
+      x0 = std::min(x0, px); x1 = std::max(x1, px); y0 = std::min(y0, py); y1 = std::max(y1, py);
+    }
+    double c0 = std::ceil(x0 - margin), c1 = std::floor(x1 + margin), r0 = std::ceil(y0 - margin), r1 = std::floor(y1 + margin);
+    if (c1 < 0 || r1 < 0 || c0 > (double)W - 1 || r0 > (double)H - 1) continue;
+    uint32_t ca = (uint32_t)std::max(0.0, c0), cb = (uint32_t)std::min((double)W - 1, c1);
+    uint32_t ra = (uint32_t)std::max(0.0, r0), rb = (uint32_t)std::min((double)H - 1, r1);
+    if (ca > cb || ra > rb) continue;
+    uint32_t wa = ca >> 5, wb = cb >> 5;
+    uint32_t first = 0xFFFFFFFFu << (ca & 31), last = 0xFFFFFFFFu >> (31 - (cb & 31));
+    for (uint32_t r = ra; r <= rb; r++) {
+      uint32_t* row = &rows[(size_t)r * wordsPerRow];
+      if (wa == wb) row[wa] |= first & last;
+      else { row[wa] |= first; for (uint32_t w = wa + 1; w < wb; w++) row[w] = 0xFFFFFFFFu; row[wb] |= last; }
+    }
+  }
+  // repack to one bit per pixel index (row * W + col)
+  size_t npix = (size_t)W * H;
+  bits.assign((npix + 31) / 32, 0u);
+  if (W % 32 == 0) { bits.assign(rows.begin(), rows.end()); return true; }
+  for (uint32_t r = 0; r < H; r++)
+    for (uint32_t c = 0; c < W; c++)
+      if ((rows[(size_t)r * wordsPerRow + (c >> 5)] >> (c & 31)) & 1u) {
+        size_t px = (size_t)r * W + c; bits[px >> 5] |= 1u << (px & 31);
+      }
+  return true;
+}
+
 }  // namespace pt

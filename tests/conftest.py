@@ -64,21 +64,4 @@ def require_gpu():
         pytest.skip('no GPU in this container (GPU tests run on the MI355X box)')
 
 
-def soup(n_tris, seed=0x5EED, extent=100.0, size=0.5):
-    """Synthetic triangle soup: centres uniform in [-extent, extent]^3, three offsets uniform in [-size, size]^3,
-    geometric normals, one grey material plus an emissive quad above (the stress scene of the 10 M-triangle config)."""
-    rng = np.random.default_rng(seed)
-    c = rng.uniform(-extent, extent, (n_tris, 1, 3)).astype(np.float32)
-    v = (c + rng.uniform(-size, size, (n_tris, 3, 3)).astype(np.float32)).astype(np.float32)
-    q = extent * 0.1
-    z = np.float32(extent * 1.1)
-    quad = np.array([[[-q, -q, z], [-q, q, z], [q, q, z]], [[-q, -q, z], [q, q, z], [q, -q, z]]], np.float32)  # faces -z
-    v = np.concatenate([v, quad]).astype(np.float32)
-    e1 = v[:, 1] - v[:, 0]; e2 = v[:, 2] - v[:, 0]
-    n = np.cross(e1, e2)
-    ln = np.linalg.norm(n, axis=1, keepdims=True); ln[ln == 0] = 1
-    n = (n / ln).astype(np.float32)
-    nrm = np.repeat(n[:, None, :], 3, axis=1).astype(np.float32)
-    mat_idx = np.zeros(len(v), np.uint32); mat_idx[-2:] = 1
-    mats = np.array([[0.0, 0.7, 0.7, 0.7], [0.5, 0.7, 0.7, 0.7]], np.float32)
-    return {'v': v, 'n': nrm, 'mat_idx': mat_idx, 'materials': mats}
+from pathtracer_amd.synthetic import soup  # noqa: E402,F401  (tests import it from here)

@@ -169,3 +169,51 @@ def test_band_partition_covers_every_row_once(height, band_rows, world):
     assert max(sizes) - min(sizes) <= band_rows
     with pytest.raises(ValueError):
         multigpu.band_share(world, world)
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_coverage_mask_is_conservative_and_tight(name, flats):
+    """The per-pixel mask view rays are culled with (rendering.d:278-285 sample positions: the pixel's nominal
+    position +- half a pixel): every sample position whose ray hits something -- front face by Scene.trace or any
+    face by Scene.hitsNothing -- lies in a pixel whose bit is set, including the extreme jitter values; and the
+    mask is not much larger than the set of pixels that can be hit."""
+    W, H = 160, 96
+    pt = P.PathTracer(W, H, device=-1)
+    pt.Scene(model_path(name))
+    cam = oracle_py.camera_lookat(30.0, H / W, CAMERAS[name][0], CAMERAS[name][1], UP)
+    pt.set_camera(cam)
+    mask = pt.coverage_mask()
+    assert mask is not None and mask.shape == (W * H,)
+    o = oracle_py.Oracle(flats[name], build_tree=False)
+    pos, d, r, u = (cam[0:3].astype(np.float64), cam[3:6].astype(np.float64), cam[6:9].astype(np.float64), cam[9:12].astype(np.float64))
+    tan_fov, aspect = float(cam[12]), float(cam[13])
+    cols, rows = np.meshgrid(np.arange(W), np.arange(H))
+    cols = cols.reshape(-1).astype(np.float64); rows = rows.reshape(-1).astype(np.float64)
+    rng = np.random.default_rng(3)
+    hit_any = np.zeros(W * H, bool)
+    lim = 1.0 - 2.0 ** -24                       # uniform(-ps, ps) is [-ps, ps): largest value just below +ps
+    jitters = [(-1.0, -1.0), (lim, lim), (-1.0, lim), (lim, -1.0), (0.0, 0.0)] + [tuple(rng.uniform(-1, lim, 2)) for _ in range(6)]
+    for jx, jy in jitters:
+        x = cols / W * 2 - 1 + jx / W
+        y = rows / H * 2 - 1 + jy / H
+        dirs = d[None, :] + r[None, :] * (x * tan_fov)[:, None] + u[None, :] * (y * tan_fov * aspect)[:, None]
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        rays = np.concatenate([np.broadcast_to(pos, dirs.shape), dirs], axis=1).astype(np.float32)
+        front = o.trace_rays(rays, kind=0)[0] >= 0
+        anyf = o.trace_rays(rays, kind=1)[0] >= 0
+        assert not (front & ~mask).any() and not (anyf & ~mask).any()
+        hit_any |= front | anyf
+    assert mask.sum() <= 1.6 * hit_any.sum() + 4 * (W + H)          # bounding rectangles of small triangles: close to the silhouette
+    if name == 'teapot':
+        assert mask.mean() < 0.5                                       # most of the frame is background
+
+
+def test_coverage_mask_unusable_when_geometry_reaches_behind_the_camera():
+    fl = soup(500, seed=2, extent=10.0)
+    pt = P.PathTracer(64, 64, device=-1)
+    pt.upload_scene(fl['v'], fl['n'], fl['mat_idx'], fl['materials'])
+    pt.set_camera(oracle_py.camera_lookat(30.0, 1.0, (0.5, 0.5, 0.5), (5, 5, 5), UP))     # camera inside the soup
+    assert pt.coverage_mask() is None
+    pt.set_camera(oracle_py.camera_lookat(30.0, 1.0, (40, 30, 200), (0, 0, 0), UP))       # outside: everything in front
+    m = pt.coverage_mask()
+    assert m is not None and 0 < m.sum() < 64 * 64
