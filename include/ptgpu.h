@@ -152,11 +152,13 @@ int ptgpu_trace_primary(PtHandle* h, uint32_t pixelOffset, uint32_t count, int32
 int ptgpu_view_rays(PtHandle* h, uint32_t pixelOffset, uint32_t count, float* rays6);
 /* First n words of RNG stream (seed, pixel, sample, stream) as the kernels draw them. */
 int ptgpu_rng_stream(PtHandle* h, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n, uint32_t* out);
-/* Parity probe (no reference counterpart): the coverage mask the view rays of getViewRay (rendering.d:278-285) are
- * culled with for the current scene and camera -- bit p of bits (ceil(width*height/32) words) set when pixel p may see
- * a triangle.  *usable = 0 when no mask can be built for this camera (a triangle reaches behind it); rendering then
- * culls by the scene's bounding box.  Works on host-only handles. */
-int ptgpu_get_coverage_mask(PtHandle* h, uint32_t* bits, uint32_t* usable);
+/* Parity probe (no reference counterpart): the masks the view rays of getViewRay (rendering.d:278-285) are culled
+ * with for the current scene and camera, ceil(width*height/32) words each, either may be NULL.  Bit p of covered is
+ * set when pixel p may see a triangle; bit p of constantSky when it cannot and in addition none of its sample
+ * positions sees sampleSky's sun disc (rendering.d:332-339), so that every sample of the pixel is the sky constant.
+ * *usable = 0 when no mask can be built for this camera (a triangle reaches behind it); rendering then culls by the
+ * scene's bounding box.  Works on host-only handles. */
+int ptgpu_get_coverage_mask(PtHandle* h, uint32_t* covered, uint32_t* constantSky, uint32_t* usable);
 
 int ptgpu_get_stats(PtHandle* h, PtStats* out);
 int ptgpu_reset_stats(PtHandle* h);

@@ -55,7 +55,7 @@ SYMBOLS = {
     'ptgpu_trace_primary': (_I, [_VP, _U32, _U32, _VP, _VP, _VP, _VP]),
     'ptgpu_view_rays': (_I, [_VP, _U32, _U32, _VP]),
     'ptgpu_rng_stream': (_I, [_VP, _U32, _U32, _U32, _U32, _VP]),
-    'ptgpu_get_coverage_mask': (_I, [_VP, _VP, _VP]),
+    'ptgpu_get_coverage_mask': (_I, [_VP, _VP, _VP, _VP]),
     'ptgpu_get_stats': (_I, [_VP, C.POINTER(PtStats)]),
     'ptgpu_reset_stats': (_I, [_VP]),
     'ptgpu_bind_accumulator': (_I, [_VP, _VP, C.c_uint64]),

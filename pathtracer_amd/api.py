@@ -234,15 +234,17 @@ class PathTracer:
         self._check(self.lib.ptgpu_rng_stream(self.h, pixel, sample, stream, n, _ptr(out)))
         return out
 
-    def coverage_mask(self):
+    def coverage_mask(self, constant_sky=False):
         """Boolean array (height*width): pixels whose view rays may hit a triangle; None when no mask can be built
-        for the current camera (rendering then culls by the scene's bounding box)."""
+        for the current camera (rendering then culls by the scene's bounding box).  constant_sky=True returns
+        (covered, constantSky): the second marks pixels all of whose samples are the sky constant."""
         npix = self.width * self.height
-        bits = np.zeros((npix + 31) // 32, np.uint32); usable = np.zeros(1, np.uint32)
-        self._check(self.lib.ptgpu_get_coverage_mask(self.h, _ptr(bits), _ptr(usable)))
+        bits = np.zeros((npix + 31) // 32, np.uint32); sky = np.zeros_like(bits); usable = np.zeros(1, np.uint32)
+        self._check(self.lib.ptgpu_get_coverage_mask(self.h, _ptr(bits), _ptr(sky), _ptr(usable)))
         if not usable[0]:
-            return None
-        return np.unpackbits(bits.view(np.uint8), bitorder='little')[:npix].astype(bool)
+            return (None, None) if constant_sky else None
+        unpack = lambda w: np.unpackbits(w.view(np.uint8), bitorder='little')[:npix].astype(bool)
+        return (unpack(bits), unpack(sky)) if constant_sky else unpack(bits)
 
     # ------------------------------------------------------------------ statistics
     def stats(self):

@@ -60,7 +60,8 @@ struct PtHandle {
   DevBuf bSlotQ, bHitA, bHitB, bRayO, bRayD, bLacc, bThr, bRng, bShO, bShD, bShW, bCounters, bStats;
   SceneBox box{};
   // coverage mask of the view rays (scene_host.h: buildCoverageMask); rebuilt when the scene or the camera changes
-  DevBuf dMask; bool maskDirty = true, maskUsable = false;
+  DevBuf dMask, dSkyMask; bool maskDirty = true, maskUsable = false;
+  ViewMasks masks() const { return maskUsable ? ViewMasks{dMask.as<uint32_t>(), dSkyMask.as<uint32_t>()} : ViewMasks{nullptr, nullptr}; }
   DevBuf bMetaDesc; std::vector<QMeta> metas;     // queue descriptors: device copy and host copy, stage-major
   Wavefront wf{}; uint32_t wfKinds = 0, wfRounds = 0;
   // statistics
@@ -311,13 +312,13 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm) 
   };
   uint32_t nslots = pm.npix * pm.k;
   wf.rayOut = h->metas[1];
-  { Timed t(h, PT_K_OTHER); launchRaygen(lc, h->box, h->maskUsable ? h->dMask.as<uint32_t>() : nullptr, dc, pm, h->acc, nslots, wf); t.done(); }
+  { Timed t(h, PT_K_OTHER); launchRaygen(lc, h->box, h->masks(), dc, pm, h->acc, nslots, wf); t.done(); }
   scan(1, 1);
   stage(1, true);
   h->st.raysPrimary += nslots; h->st.samples += nslots;
   if (dc.mode == 1)      // depth 0..maxDepth can still spawn a ray (the check is depth > maxDepth, rendering.d:380)
     for (uint32_t round = 0; round <= dc.maxDepth; round++) stage(round + 2, false);
-  { Timed t(h, PT_K_ACCUM); launchAccumulate(lc, dc, pm, h->acc, wf); t.done(); }
+  { Timed t(h, PT_K_ACCUM); launchAccumulate(lc, h->masks(), dc, pm, h->acc, wf); t.done(); }
   HIPCHECK(hipGetLastError());
 }
 
@@ -340,12 +341,14 @@ void renderPixels(PtHandle* h, PixMap base, uint64_t totalPix, uint32_t spp) {
   if (totalPix == 0 || spp == 0) return;
   ensureWavefront(h);
   if (h->maskDirty) {
-    std::vector<uint32_t> bits;
-    h->maskUsable = !(h->cfg.flags & PT_FLAG_NO_COVERAGE_MASK) && buildCoverageMask(h->flat, h->cam, h->cfg.width, h->cfg.height, bits);
+    std::vector<uint32_t> bits, sky;
+    h->maskUsable = !(h->cfg.flags & PT_FLAG_NO_COVERAGE_MASK) &&
+                    buildCoverageMask(h->flat, h->cam, h->cfg.width, h->cfg.height, bits, sky);
     if (h->maskUsable) {
       HIPCHECK(hipStreamSynchronize(h->stream));
-      h->dMask.alloc(bits.size() * 4);
+      h->dMask.alloc(bits.size() * 4); h->dSkyMask.alloc(sky.size() * 4);
       HIPCHECK(hipMemcpy(h->dMask.p, bits.data(), bits.size() * 4, hipMemcpyHostToDevice));
+      HIPCHECK(hipMemcpy(h->dSkyMask.p, sky.data(), sky.size() * 4, hipMemcpyHostToDevice));
     }
     h->maskDirty = false;
   }
@@ -679,15 +682,16 @@ int ptgpu_view_rays(PtHandle* h, uint32_t off, uint32_t count, float* rays6) {
   });
 }
 
-int ptgpu_get_coverage_mask(PtHandle* h, uint32_t* bits, uint32_t* usable) {
+int ptgpu_get_coverage_mask(PtHandle* h, uint32_t* covered, uint32_t* constantSky, uint32_t* usable) {
   return guarded([&]() {
     if (!h || !usable) fail(PT_E_INVALID, "null argument");
     if (!h->haveScene) fail(PT_E_STATE, "no scene");
     if (!h->haveCamera) fail(PT_E_STATE, "no camera");
-    std::vector<uint32_t> m;
-    bool ok = buildCoverageMask(h->flat, h->cam, h->cfg.width, h->cfg.height, m);
+    std::vector<uint32_t> m, s;
+    bool ok = buildCoverageMask(h->flat, h->cam, h->cfg.width, h->cfg.height, m, s);
     *usable = ok ? 1u : 0u;
-    if (ok && bits) std::memcpy(bits, m.data(), m.size() * 4);
+    if (ok && covered) std::memcpy(covered, m.data(), m.size() * 4);
+    if (ok && constantSky) std::memcpy(constantSky, s.data(), s.size() * 4);
   });
 }
 

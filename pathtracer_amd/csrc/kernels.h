@@ -44,6 +44,12 @@ struct DevScene {
 // raygen than those rays cost in extend.)
 struct SceneBox { float mn[3], mx[3]; };
 
+// Per-pixel bit masks of the view rays (scene_host.h: buildCoverageMask), both null when no mask is in use.
+//   covered      some triangle's screen rectangle reaches the pixel: its view rays are traced
+//   constantSky  not covered and every sample of the pixel misses sampleSky's sun disc: each sample's radiance is
+//                the same constant, raygen skips the slot and accumulate adds the constant without reading it
+struct ViewMasks { const uint32_t* covered; const uint32_t* constantSky; };
+
 struct DevCfg {               // PtConfig + camera as the kernels need them
   uint32_t W, H, mode, hasSky, hasLights;
   V3 sunDir, sunRadiance, skyRadiance;
@@ -139,8 +145,8 @@ enum { STAT_RAYS_LIGHT = 0, STAT_RAYS_INDIRECT, STAT_RAYS_OCCL, STAT_NODES_CLOSE
 struct LaunchCfg { int device; int numCUs; bool countVisits; hipStream_t stream; };
 
 // ---- wavefront stages (all asynchronous on lc.stream) ----
-// mask: one bit per frame pixel (scene_host.h: buildCoverageMask), or null to cull by the scene box
-void launchRaygen(const LaunchCfg& lc, const SceneBox& box, const uint32_t* mask, const DevCfg& cfg, const PixMap& pm,
+// masks.covered == null: cull by the scene box
+void launchRaygen(const LaunchCfg& lc, const SceneBox& box, const ViewMasks& masks, const DevCfg& cfg, const PixMap& pm,
                   const float4* acc, uint32_t nslots, const Wavefront& wf);
 // prefix sums + consumer start segments for n queues, and zeroing of the stage's dynamic task counters
 void launchScan(const LaunchCfg& lc, const QMeta* metas, int n, uint32_t* taskCounters);
@@ -151,7 +157,8 @@ void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, con
                  const Wavefront& wf, bool primary);
 void launchConnect(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, float area);
 void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind);
-void launchAccumulate(const LaunchCfg& lc, const DevCfg& cfg, const PixMap& pm, float4* acc, const Wavefront& wf);
+void launchAccumulate(const LaunchCfg& lc, const ViewMasks& masks, const DevCfg& cfg, const PixMap& pm, float4* acc,
+                      const Wavefront& wf);
 
 // ---- stand-alone operators ----
 void launchExtendPrimary(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,

@@ -369,11 +369,17 @@ __device__ __forceinline__ bool nextChunk(WorkPool* p, uint32_t* counter, const 
 
 // (pixel, sample index, view ray) of path slot i: getViewRay, rendering.d:278-285
 struct PrimaryRay { uint32_t gp, sampleIdx; V3 d; Rng g; };
-__device__ __forceinline__ PrimaryRay primaryRay(const DevCfg& cfg, const PixMap& pm, const float4* __restrict__ acc, uint32_t i,
-                                                 bool jitter) {
+// frame pixel and sample number (within the batch) of path slot i
+__device__ __forceinline__ uint32_t slotPixel(const DevCfg& cfg, const PixMap& pm, uint32_t i, uint32_t& s) {
+  s = fdiv(pm.divNpix, i);
+  return mapPixel(pm, cfg.W, i - s * pm.npix);
+}
+__device__ __forceinline__ bool maskBit(const uint32_t* __restrict__ m, uint32_t p) { return (m[p >> 5] >> (p & 31u)) & 1u; }
+
+__device__ __forceinline__ PrimaryRay primaryRayAt(const DevCfg& cfg, const float4* __restrict__ acc, uint32_t gp, uint32_t s,
+                                                   bool jitter) {
   PrimaryRay r;
-  uint32_t s = fdiv(pm.divNpix, i), lp = i - s * pm.npix;
-  r.gp = mapPixel(pm, cfg.W, lp);
+  r.gp = gp;
   uint32_t row = fdiv(cfg.divW, r.gp), col = r.gp - row * cfg.W;
   float x, y;
   if (jitter) {
@@ -387,6 +393,11 @@ __device__ __forceinline__ PrimaryRay primaryRay(const DevCfg& cfg, const PixMap
   r.d = screenRayDir(cfg.cam, x, y);
   return r;
 }
+__device__ __forceinline__ PrimaryRay primaryRay(const DevCfg& cfg, const PixMap& pm, const float4* __restrict__ acc, uint32_t i,
+                                                 bool jitter) {
+  uint32_t s, gp = slotPixel(cfg, pm, i, s);
+  return primaryRayAt(cfg, acc, gp, s, jitter);
+}
 
 // ------------------------------------------------------------------------------------------------ raygen
 // Block-task T = blockIdx.x covers slots [T*P, (T+1)*P).  A view ray that misses the scene's box cannot hit
@@ -395,8 +406,9 @@ __device__ __forceinline__ PrimaryRay primaryRay(const DevCfg& cfg, const PixMap
 // registers: the test costs no memory traffic.
 // With a coverage mask (one bit per pixel: some triangle's screen rectangle, grown by the sample jitter, overlaps
 // the pixel) the bit decides instead of the box: for an object in front of a background it culls nearly every ray
-// that would traverse the tree and come back empty.
-__global__ void __launch_bounds__(256) k_raygen(SceneBox box, const uint32_t* __restrict__ mask, DevCfg cfg, PixMap pm,
+// that would traverse the tree and come back empty.  Pixels of the constant-sky mask are skipped altogether: each
+// of their samples is the sky constant, which accumulate adds without reading anything.
+__global__ void __launch_bounds__(256) k_raygen(SceneBox box, ViewMasks masks, DevCfg cfg, PixMap pm,
                                                 const float4* __restrict__ acc, uint32_t nslots, Wavefront wf) {
   __shared__ uint32_t sCnt;
   if (threadIdx.x == 0) sCnt = 0;
@@ -408,15 +420,18 @@ __global__ void __launch_bounds__(256) k_raygen(SceneBox box, const uint32_t* __
     bool enter = false;
     V3 d = v3(0, 0, 0);
     if (i < end) {
-      PrimaryRay pr = primaryRay(cfg, pm, acc, i, true);
-      d = pr.d;
-      if (mask) enter = (mask[pr.gp >> 5] >> (pr.gp & 31u)) & 1u;
+      uint32_t s, gp = slotPixel(cfg, pm, i, s);
+      if (masks.constantSky && maskBit(masks.constantSky, gp)) culled++;
       else {
-        RayInv ri = makeRayInv(cfg.cam.pos, d);
-        float tn;
-        enter = slab(ri, box.mn[0], box.mn[1], box.mn[2], box.mx[0], box.mx[1], box.mx[2], PT_FLT_MAX, tn);
+        d = primaryRayAt(cfg, acc, gp, s, true).d;
+        if (masks.covered) enter = maskBit(masks.covered, gp);
+        else {
+          RayInv ri = makeRayInv(cfg.cam.pos, d);
+          float tn;
+          enter = slab(ri, box.mn[0], box.mn[1], box.mn[2], box.mx[0], box.mx[1], box.mx[2], PT_FLT_MAX, tn);
+        }
+        if (!enter) { wf.Lacc[i] = f4(sampleSky(d), 0.0f); culled++; }        // rendering.d:480
       }
-      if (!enter) { wf.Lacc[i] = f4(sampleSky(d), 0.0f); culled++; }          // rendering.d:480
     }
     uint32_t idx = waveAppend(enter, &sCnt);
     if (enter) wf.slotQ[T * segCap + idx] = f4(d, u2f(i));
@@ -742,11 +757,18 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, DevCfg cfg, PixMap p
 // ------------------------------------------------------------------------------------------------ accumulate
 // pixel.sum += L; pixel.n += 1 for each of the batch's k samples of a pixel, in sample order
 // (rendering.d:477-482; the (sum / N) of the indirect chains as in the block at rendering.d:474-477).
-__global__ void __launch_bounds__(256) k_accumulate(DevCfg cfg, PixMap pm, float4* __restrict__ acc, Wavefront wf) {
+__global__ void __launch_bounds__(256) k_accumulate(ViewMasks masks, DevCfg cfg, PixMap pm, float4* __restrict__ acc, Wavefront wf) {
   uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
   if (lp >= pm.npix) return;
   uint32_t gp = mapPixel(pm, cfg.W, lp);
   float4 a = acc[gp];
+  if (masks.constantSky && maskBit(masks.constantSky, gp)) {
+    // every sample of this pixel is sampleSky away from its sun disc (rendering.d:338); raygen wrote nothing
+    const V3 c = v3(0.682f, 0.977f, 1.0f);
+    for (uint32_t s = 0; s < pm.k; s++) { a.x += c.x; a.y += c.y; a.z += c.z; a.w += 1.0f; }
+    acc[gp] = a;
+    return;
+  }
   for (uint32_t s = 0; s < pm.k; s++) {
     uint32_t slot = s * pm.npix + lp;
     float4 L = wf.Lacc[slot];
@@ -867,9 +889,9 @@ void allowLds(const LaunchCfg& lc, const void* kernel, size_t bytes) {
     else hipLaunchKernelGGL((KERNEL<false, false>), g.grid, g.block, 0, lc.stream, __VA_ARGS__);          \
   } while (0)
 
-void launchRaygen(const LaunchCfg& lc, const SceneBox& box, const uint32_t* mask, const DevCfg& cfg, const PixMap& pm,
+void launchRaygen(const LaunchCfg& lc, const SceneBox& box, const ViewMasks& masks, const DevCfg& cfg, const PixMap& pm,
                   const float4* acc, uint32_t nslots, const Wavefront& wf) {
-  hipLaunchKernelGGL(k_raygen, dim3(PT_SEGS), dim3(256), 0, lc.stream, box, mask, cfg, pm, acc, nslots, wf);
+  hipLaunchKernelGGL(k_raygen, dim3(PT_SEGS), dim3(256), 0, lc.stream, box, masks, cfg, pm, acc, nslots, wf);
 }
 
 void launchScan(const LaunchCfg& lc, const QMeta* metas, int n, uint32_t* taskCounters) {
@@ -920,8 +942,9 @@ void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, con
   else hipLaunchKernelGGL(k_shade<false>, dim3(PT_SEGS), dim3(256), 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
 }
 
-void launchAccumulate(const LaunchCfg& lc, const DevCfg& cfg, const PixMap& pm, float4* acc, const Wavefront& wf) {
-  hipLaunchKernelGGL(k_accumulate, dim3((pm.npix + 255) / 256), dim3(256), 0, lc.stream, cfg, pm, acc, wf);
+void launchAccumulate(const LaunchCfg& lc, const ViewMasks& masks, const DevCfg& cfg, const PixMap& pm, float4* acc,
+                      const Wavefront& wf) {
+  hipLaunchKernelGGL(k_accumulate, dim3((pm.npix + 255) / 256), dim3(256), 0, lc.stream, masks, cfg, pm, acc, wf);
 }
 
 void launchViewRays(const LaunchCfg& lc, const DevCfg& cfg, uint32_t pixelOffset, uint32_t count, float* rays6) {

@@ -160,7 +160,8 @@ Camera cameraLookAt(float fovDegrees, float aspect, V3 from, V3 to, V3 up) {
   return c;
 }
 
-bool buildCoverageMask(const FlatScene& scene, const Camera& cam, uint32_t W, uint32_t H, std::vector<uint32_t>& bits) {
+bool buildCoverageMask(const FlatScene& scene, const Camera& cam, uint32_t W, uint32_t H, std::vector<uint32_t>& bits,
+                       std::vector<uint32_t>& constantSky) {
   // A view ray through screen position (x, y) has direction dir + right*(x*tanFov) + up*(y*tanFov*aspect)
   // (camera.d:38-42).  Point p (relative to the camera) lies on it iff p = t*(dir + a*right + b*up) with t > 0,
   // x = a/tanFov, y = b/(tanFov*aspect): solve with the inverse of the matrix whose columns are dir, right, up.
@@ -216,15 +217,31 @@ bool buildCoverageMask(const FlatScene& scene, const Camera& cam, uint32_t W, ui
       else { row[wa] |= first; for (uint32_t w = wa + 1; w < wb; w++) row[w] = 0xFFFFFFFFu; row[wb] |= last; }
     }
   }
-  // repack to one bit per pixel index (row * W + col)
+  // repack to one bit per pixel index (row * W + col); constantSky: not covered and no sample position of the pixel
+  // can see sampleSky's sun disc (dot(normalized(1,1,6), d) > 0.997, rendering.d:332-339).  The direction of a
+  // sample differs from that of the pixel's nominal position by an angle of at most delta / (|v| - delta), v the
+  // un-normalised direction and delta the length of the jitter's offset to it; a cosine changes by no more than
+  // the angle does.
   size_t npix = (size_t)W * H;
   bits.assign((npix + 31) / 32, 0u);
-  if (W % 32 == 0) { bits.assign(rows.begin(), rows.end()); return true; }
-  for (uint32_t r = 0; r < H; r++)
-    for (uint32_t c = 0; c < W; c++)
-      if ((rows[(size_t)r * wordsPerRow + (c >> 5)] >> (c & 31)) & 1u) {
-        size_t px = (size_t)r * W + c; bits[px >> 5] |= 1u << (px & 31);
-      }
+  constantSky.assign((npix + 31) / 32, 0u);
+  const double sun[3] = {1.0 / std::sqrt(38.0), 1.0 / std::sqrt(38.0), 6.0 / std::sqrt(38.0)};
+  const double rl = std::sqrt((double)dot(cam.right, cam.right)), ul = std::sqrt((double)dot(cam.up, cam.up));
+  const double delta = std::sqrt((rl * sx / W) * (rl * sx / W) + (ul * sy / H) * (ul * sy / H));
+  for (uint32_t r = 0; r < H; r++) {
+    double y = (double)r / H * 2.0 - 1.0;
+    for (uint32_t c = 0; c < W; c++) {
+      size_t px = (size_t)r * W + c;
+      if ((rows[(size_t)r * wordsPerRow + (c >> 5)] >> (c & 31)) & 1u) { bits[px >> 5] |= 1u << (px & 31); continue; }
+      double x = (double)c / W * 2.0 - 1.0;
+      double v[3] = {cam.dir.x + cam.right.x * x * sx + cam.up.x * y * sy, cam.dir.y + cam.right.y * x * sx + cam.up.y * y * sy,
+                     cam.dir.z + cam.right.z * x * sx + cam.up.z * y * sy};
+      double len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      if (!(len > 2.0 * delta)) continue;                                  // degenerate direction: leave it to the kernel
+      double cosSun = (v[0] * sun[0] + v[1] * sun[1] + v[2] * sun[2]) / len;
+      if (cosSun + delta / (len - delta) + 1e-5 < 0.997) constantSky[px >> 5] |= 1u << (px & 31);
+    }
+  }
   return true;
 }
 

@@ -142,6 +142,35 @@ def test_full_batches_where_nearly_every_ray_hits(require_gpu, flats):
     assert hit.mean() > 0.95
 
 
+def test_background_with_the_sun_disc_in_view_is_bit_identical(require_gpu):
+    """Camera looking along sampleSky's sun direction (rendering.d:332-339): background pixels inside or at the edge
+    of the disc are evaluated per sample, those away from it are filled by the constant-sky shortcut; both must equal
+    the oracle bit for bit (no sin/cos is involved in a miss).  Also with the masks switched off."""
+    from conftest import soup, UP
+    W, H, spp = 96, 64, 8
+    fl = soup(300, seed=4, extent=6.0)
+    cam = oracle_py.camera_lookat(30.0, H / W, (-20, -20, -120), (0, 0, 0), UP)
+    o = oracle_py.Oracle(fl, build_tree=False)
+    o.configure(width=W, height=H, has_sky=True, seed=11)
+    o.set_camera(cam)
+    ref = oracle_py.new_pixels(W * H); o.render_keyed(ref, 0, spp, nthreads=8)
+    for flags in (0, P.PT_FLAG_NO_COVERAGE_MASK):
+        pt = P.PathTracer(W, H, device=0, has_sky=1, seed=11, flags=flags)
+        pt.upload_scene(fl['v'], fl['n'], fl['mat_idx'], fl['materials'])
+        pt.set_camera(cam)
+        covered, const_sky = pt.coverage_mask(constant_sky=True)
+        assert const_sky.any() and (~covered & ~const_sky).any()          # both kinds of background pixel occur
+        pt.render_frame(spp)
+        got = pt.read_pixels()
+        bg = ~covered
+        assert (got['n'] == spp).all()
+        assert np.array_equal(got['sum'][bg].view(np.uint32), ref['sum'][bg].view(np.uint32))
+        assert (got['sum'][bg].max(1) > 30 * spp * 0.5).any()              # the disc itself (radiance 30) is in there
+        assert rel_rmse(got['color'], ref['color']) < 2e-3
+        st = pt.stats()
+        assert st.raysPrimary == W * H * spp and st.raysCulled >= (bg.sum() * spp if flags == 0 else 0)
+
+
 def test_band_and_sample_splits_reassemble_bit_identically(require_gpu):
     """Two handles stand in for two GPUs: interleaved 4-scanline bands summed == one GPU; sample slices summed ==
     the per-slice images added."""

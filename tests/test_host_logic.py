@@ -217,3 +217,37 @@ def test_coverage_mask_unusable_when_geometry_reaches_behind_the_camera():
     pt.set_camera(oracle_py.camera_lookat(30.0, 1.0, (40, 30, 200), (0, 0, 0), UP))       # outside: everything in front
     m = pt.coverage_mask()
     assert m is not None and 0 < m.sum() < 64 * 64
+
+
+def test_constant_sky_mask_never_hides_the_sun_disc_or_geometry():
+    """constantSky pixels are skipped by raygen and filled with sampleSky's plain constant by accumulate
+    (rendering.d:332-339): none of their sample positions may hit geometry or fall inside the sun disc
+    dot(normalized(1,1,6), d) > 0.997."""
+    W, H = 96, 64
+    fl = soup(300, seed=4, extent=6.0)
+    pt = P.PathTracer(W, H, device=-1)
+    pt.upload_scene(fl['v'], fl['n'], fl['mat_idx'], fl['materials'])
+    cam = oracle_py.camera_lookat(30.0, H / W, (-20, -20, -120), (0, 0, 0), UP)          # looks along (1, 1, 6): at the sun
+    pt.set_camera(cam)
+    covered, const_sky = pt.coverage_mask(constant_sky=True)
+    assert covered is not None and not (covered & const_sky).any()
+    pos, d, r, u = (cam[0:3].astype(np.float64), cam[3:6].astype(np.float64), cam[6:9].astype(np.float64), cam[9:12].astype(np.float64))
+    tan_fov, aspect = float(cam[12]), float(cam[13])
+    cols, rows = np.meshgrid(np.arange(W), np.arange(H))
+    cols = cols.reshape(-1).astype(np.float64); rows = rows.reshape(-1).astype(np.float64)
+    sun = np.array([1.0, 1.0, 6.0]) / np.sqrt(38.0)
+    lim = 1.0 - 2.0 ** -24
+    rng = np.random.default_rng(5)
+    sunny = np.zeros(W * H, bool)
+    for jx, jy in [(-1.0, -1.0), (lim, lim), (-1.0, lim), (lim, -1.0), (0.0, 0.0)] + [tuple(rng.uniform(-1, lim, 2)) for _ in range(8)]:
+        x = cols / W * 2 - 1 + jx / W
+        y = rows / H * 2 - 1 + jy / H
+        dirs = d[None, :] + r[None, :] * (x * tan_fov)[:, None] + u[None, :] * (y * tan_fov * aspect)[:, None]
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        sunny |= dirs @ sun > 0.997 - 1e-6
+    assert sunny.any() and not (sunny & const_sky).any()
+    assert const_sky.sum() > 0.3 * W * H                                   # and it still removes most of the background
+    # a camera that looks away from the sun: everything that is not covered is constant
+    pt.set_camera(oracle_py.camera_lookat(30.0, H / W, (20, 20, 120), (0, 0, 0), UP))
+    covered, const_sky = pt.coverage_mask(constant_sky=True)
+    assert np.array_equal(const_sky, ~covered)
