@@ -222,17 +222,27 @@ uint32_t numKinds(const PtHandle* h) { return h->dsc.numLightGroups + 2; }
 
 void ensureWavefront(PtHandle* h) {
   const PtConfig& c = h->cfg;
-  // Large batches keep every launch far above the 2048 threads x 256 CUs that are resident at once (a 4 M-slot
-  // batch leaves ~1.4 shadow rays per resident thread and the tail dominates); HBM has room: ~210 B per slot.
-  uint64_t want = c.batchSlots ? c.batchSlots : (c.mode == 1 ? (1u << 22) : (1u << 24));
+  // Large batches: every launch ends with a tail in which the last waves finish alone, and a batch is ~10 launches.
+  // Measured on the 1080p teapot frame (ms per 256 spp): 4 M slots 70, 16 M 31.6, 32 M 28.0, 64 M 26.8, 128 M 26.4.
+  // HBM has room: 160 B per slot in mode 0 with two shadow kinds (64 M slots = 10.7 GB), ~1.3 KB in mode 1.
+  uint64_t want = c.batchSlots ? c.batchSlots : (c.mode == 1 ? (1u << 23) : (1u << 26));
   uint64_t frame = (uint64_t)c.width * c.height;
   // no point in more slots than 64 samples of the whole frame; a multiple of 64 * PT_SEGS so that every block-task's
   // share of a full batch is whole waves and fits its output segment
   const uint64_t gran = 64ull * PT_SEGS;
   want = std::min<uint64_t>(want, frame * 64);
-  uint32_t capSlots = (uint32_t)std::min<uint64_t>(((want + gran - 1) / gran) * gran, 0x40000000ull);
   uint32_t NI = c.mode == 1 ? c.numIndirect : 0;
   uint32_t lanes = 1 + NI;
+  if (!c.batchSlots) {       // the default yields to the memory that is actually free (the caller may hold most of it)
+    // decided once per shape of the wavefront state, not per render call
+    if (h->wf.capSlots && h->wf.lanes == lanes && h->wfKinds == numKinds(h) && h->wfRounds == (c.mode == 1 ? c.maxDepth + 4 : 2)) return;
+    size_t freeB = 0, totalB = 0;
+    HIPCHECK(hipMemGetInfo(&freeB, &totalB));
+    uint64_t perSlot = 16 + 16ull * lanes + (NI ? 24ull * lanes : 0) + (uint64_t)std::max(1u, NI) * (32 + (NI ? 32 : 0) + 48ull * numKinds(h));
+    uint64_t held = h->wf.capSlots ? (uint64_t)h->wf.capSlots * perSlot : 0;       // what this handle would give back
+    while (want > gran && want * perSlot > (freeB + held) / 2) want /= 2;
+  }
+  uint32_t capSlots = (uint32_t)std::min<uint64_t>(((want + gran - 1) / gran) * gran, 0x40000000ull);
   uint64_t capQueue = (uint64_t)capSlots * std::max(1u, NI);
   if (capQueue > 0x7FFFFFFFull) fail(PT_E_INVALID, "batchSlots * numIndirect too large");
   uint32_t kinds = numKinds(h), rounds = c.mode == 1 ? c.maxDepth + 4 : 2;

@@ -105,6 +105,14 @@ __device__ __forceinline__ bool slab(const RayInv& r, float mnx, float mny, floa
 
 struct Hit { float t, u, v; uint32_t tri; };
 
+// Workgroup sizes of the kernels that run as PT_SEGS static block-tasks.
+#ifndef PT_RAYGEN_THREADS
+#define PT_RAYGEN_THREADS 256
+#endif
+#ifndef PT_SHADE_THREADS
+#define PT_SHADE_THREADS 256
+#endif
+
 // Traversal kernels are compiled for 8 waves per SIMD: two 1024-thread workgroups per CU when the scene copy in LDS
 // leaves room.  Besides 64 VGPRs this bounds the scalar registers: with more than 80 of them a SIMD holds only 7
 // waves, and a second 16-wave workgroup no longer fits on the CU.
@@ -426,7 +434,7 @@ __device__ __forceinline__ PrimaryRay primaryRay(const DevCfg& cfg, const PixMap
 // the pixel) the bit decides instead of the box: for an object in front of a background it culls nearly every ray
 // that would traverse the tree and come back empty.  Pixels of the constant-sky mask are skipped altogether: each
 // of their samples is the sky constant, which accumulate adds without reading anything.
-__global__ void __launch_bounds__(256) k_raygen(SceneBox box, ViewMasks masks, DevCfg cfg, PixMap pm,
+__global__ void __launch_bounds__(PT_RAYGEN_THREADS) k_raygen(SceneBox box, ViewMasks masks, DevCfg cfg, PixMap pm,
                                                 const float4* __restrict__ acc, uint32_t nslots, Wavefront wf) {
   __shared__ uint32_t sCnt;
   if (threadIdx.x == 0) sCnt = 0;
@@ -712,7 +720,7 @@ __device__ __forceinline__ void directLight(ShadeCtx& cx, bool active, Rng& g, V
 // Block-task T = blockIdx.x reads flat entries [T*P, (T+1)*P) of the hit queue and fills segment T of the
 // output queues.
 template <bool PRIMARY>
-__global__ void __launch_bounds__(256) k_shade(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, Wavefront wf,
+__global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, Wavefront wf,
                                                int numKinds) {
   __shared__ uint32_t sCnt[1 + PT_MAX_KINDS];
   if (threadIdx.x <= PT_MAX_KINDS) sCnt[threadIdx.x] = 0;
@@ -882,6 +890,8 @@ Geo traversalGeo(const LaunchCfg& lc, const DevScene& sc, uint64_t maxItems) {
   else if (sc.ldsBytes <= 78 * 1024) { bs = 1024; perCU = 2; }
   else { bs = 1024; perCU = 1; }
   uint64_t want = (maxItems + bs - 1) / bs;
+  static const char* envDiv = getenv("PTGPU_X_PER_CU_DIV");
+  if (envDiv) perCU = std::max(1u, perCU / (uint32_t)atoi(envDiv));
   uint64_t cap = (uint64_t)lc.numCUs * perCU;
   g.block = dim3(bs); g.grid = dim3((unsigned)std::max<uint64_t>(1, std::min(want, cap)));
   return g;
@@ -909,7 +919,7 @@ void allowLds(const LaunchCfg& lc, const void* kernel, size_t bytes) {
 
 void launchRaygen(const LaunchCfg& lc, const SceneBox& box, const ViewMasks& masks, const DevCfg& cfg, const PixMap& pm,
                   const float4* acc, uint32_t nslots, const Wavefront& wf) {
-  hipLaunchKernelGGL(k_raygen, dim3(PT_SEGS), dim3(256), 0, lc.stream, box, masks, cfg, pm, acc, nslots, wf);
+  hipLaunchKernelGGL(k_raygen, dim3(PT_SEGS), dim3(PT_RAYGEN_THREADS), 0, lc.stream, box, masks, cfg, pm, acc, nslots, wf);
 }
 
 void launchScan(const LaunchCfg& lc, const QMeta* metas, int n, uint32_t* taskCounters) {
@@ -956,8 +966,8 @@ void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, 
 void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
                  const Wavefront& wf, bool primary) {
   int numKinds = (cfg.hasLights ? (int)sc.numLightGroups : 0) + (cfg.hasSky ? 2 : 0);
-  if (primary) hipLaunchKernelGGL(k_shade<true>, dim3(PT_SEGS), dim3(256), 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
-  else hipLaunchKernelGGL(k_shade<false>, dim3(PT_SEGS), dim3(256), 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+  if (primary) hipLaunchKernelGGL(k_shade<true>, dim3(PT_SEGS), dim3(PT_SHADE_THREADS), 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+  else hipLaunchKernelGGL(k_shade<false>, dim3(PT_SEGS), dim3(PT_SHADE_THREADS), 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
 }
 
 void launchAccumulate(const LaunchCfg& lc, const ViewMasks& masks, const DevCfg& cfg, const PixMap& pm, float4* acc,
