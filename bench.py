@@ -160,6 +160,10 @@ def main():
                         visits_per_ray={k: round(v, 4) for k, v in visits.items()},
                         note='scene (nodes+triangles) is LDS-resident: algorithmic node/triangle bytes are served from LDS, '
                              'HBM carries only the ray/hit/shadow-queue streams' if st.sceneInLds else 'scene traversed from HBM/L2')
+        if traffic and dom_ms > 0:      # what the kernel really moves over HBM: measured bytes / live launch duration
+            hbm = traffic / (dom_ms / max(1, dom_launch) * 1e-3) / 1e9
+            roofline['measured_hbm_GBps'] = round(hbm, 1)
+            roofline['measured_hbm_frac'] = round(hbm / HBM_PEAK_GBS, 4)
 
         cpu = None
         if world == 1 and args.cpu_seconds > 0 and wl['model'] != 'soup':     # the oracle's O(T^2) tree build rules the soup out
@@ -178,7 +182,7 @@ def main():
                        'bvh_nodes': int(st.numNodes)},
             'spp_per_s': round(samples / (W * H) / elapsed, 2), 'Msamples_per_s': round(samples / elapsed / 1e6, 2),
             'rays_per_sample': round(rays / max(1.0, samples), 4),
-            'rays': {'primary': int(st.raysPrimary), 'primary_culled_by_scene_box': int(st.raysCulled),
+            'rays': {'primary': int(st.raysPrimary), 'primary_answered_in_raygen': int(st.raysCulled),
                      'light': int(st.raysLight), 'indirect': int(st.raysIndirect), 'occlusion': int(st.raysOcclusion)},
             'device_ms_per_step_rank0': round(st.renderMs / args.steps, 3), 'readback_ms': round(readback_ms, 3),
             'kernels': kern, 'roofline': roofline, 'cpu_baseline': cpu,

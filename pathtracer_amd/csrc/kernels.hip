@@ -120,13 +120,8 @@ struct Hit { float t, u, v; uint32_t tri; };
 
 // One triangle of a leaf: the two-sided Moeller-Trumbore test in the fixed evaluation order of pt_math.h.
 // ANY: returns true when the hit is accepted (Scene.hitsNothing stops there).  Otherwise updates the closest
-// front-face hit and returns false.
-#ifndef PT_X_TRI_FLAT
-#define PT_X_TRI_FLAT 0
-#endif
-#ifndef PT_X_PUSH_FLAT
-#define PT_X_PUSH_FLAT 0
-#endif
+// front-face hit and returns false.  (A straight-line form with one combined predicate instead of the nested
+// rejections was measured: the vector work of rejected triangles outweighs the exec-mask regions it removes.)
 template <bool ANY, bool LDSS>
 __device__ __forceinline__ bool testTriangle(const DevScene& sc, uint32_t row, V3 o, V3 d, float eps, Hit& h, bool& found) {
   float4 t0 = ldTri<LDSS>(sc, row), tA = ldTri<LDSS>(sc, row + 1), tB = ldTri<LDSS>(sc, row + 2);
@@ -134,26 +129,6 @@ __device__ __forceinline__ bool testTriangle(const DevScene& sc, uint32_t row, V
   V3 A = xyz(tA), B = xyz(tB);
   V3 p = cross(d, B);
   float det = dot(A, p);
-#if PT_X_TRI_FLAT
-  // Straight-line form: the reference's nested rejections (det, u, v) become one combined predicate.  The values are
-  // the same (for a rejected triangle they are computed and discarded; a division by a tiny det only yields inf/NaN
-  // that the predicate masks); what goes away is one exec-mask region per nesting level.
-  V3 s = o - xyz(t0);
-  float inv = 1.0f / det;
-  float u = dot(s, p) * inv;
-  V3 q = cross(s, A);
-  float v = dot(d, q) * inv;
-  float t = dot(B, q) * inv;
-  uint32_t orig = f2u(t0.w);
-  bool inside = !(fabsf(det) < eps) & !(u < 0.0f || u > 1.0f) & !(v < 0.0f || u + v > 1.0f);
-  if (ANY) {
-    if (inside & (t >= eps)) { h.t = t; h.u = u; h.v = v; h.tri = orig; return true; }
-  } else {
-    // pos < rayPos && pos >= FloatEpsilon, then front face; equal t keeps the lower triangle id
-    bool take = inside & (t < h.t || (t == h.t && orig < h.tri)) & (t >= eps) & (det < 0.0f);
-    h.t = take ? t : h.t; h.u = take ? u : h.u; h.v = take ? v : h.v; h.tri = take ? orig : h.tri; found = found | take;
-  }
-#else
   if (!(fabsf(det) < eps)) {
     V3 s = o - xyz(t0);
     float inv = 1.0f / det;
@@ -175,7 +150,6 @@ __device__ __forceinline__ bool testTriangle(const DevScene& sc, uint32_t row, V
       }
     }
   }
-#endif
   return false;
 }
 
@@ -206,40 +180,62 @@ __device__ __forceinline__ uint32_t stepDown(const DevScene& sc, const RayInv& r
   uint32_t r0 = f2u(a0.w), r1 = f2u(b0.w);
   bool sw = h1 && (!h0 || tn1 < tn0);
   uint32_t nearRef = sw ? r1 : r0, farRef = sw ? r0 : r1;
-#if PT_X_PUSH_FLAT
-  stack[sp] = farRef;                  // unconditional store above the top; the depth bound of the tree leaves room
-  sp += (h0 && h1) ? 1 : 0;
-#else
-  if (h0 && h1) stack[sp++] = farRef;
-#endif
+  if (h0 && h1) stack[sp++] = farRef;  // (storing unconditionally above the top was measured: 20 % slower)
   if (h0 || h1) return nearRef;
   if (sp == 0) return PT_NONE;
   return popRef(stack, sp);
 }
 __device__ __forceinline__ bool isInternal(uint32_t ref) { return (ref >> BVH_COUNT_SHIFT) == 0; }
+__device__ __forceinline__ bool isLeaf(uint32_t ref) { return (ref >> BVH_COUNT_SHIFT) != 0 && ref != PT_NONE; }
 
 // Closest front-face hit (ANY = false: Scene.trace, scene.d:691-740) or first hit of either face
-// (ANY = true: Scene.hitsNothing, scene.d:808-835).  Returns true if something was accepted.  A leaf is tested as
-// soon as it is reached.  (Postponing a lane's first leaf until the other lanes of the wave have found theirs,
-// so that leaves are tested together, was measured: the bookkeeping costs more vector instructions than the
-// better lane utilisation saves once the kernels run at full occupancy.)  COUNT counts box and triangle tests.
+// (ANY = true: Scene.hitsNothing, scene.d:808-835).  Returns true if something was accepted.  COUNT counts box and
+// triangle tests.
+//
+// POSTPONE = false: a leaf is tested as soon as it is reached (the canonical order, and the one the counters use).
+// POSTPONE = true: a lane keeps its first leaf back and goes on descending until no lane of the wave is still
+// looking for its first leaf; then the wave tests leaves together.  The extra boxes tested with a not yet shortened
+// ray do not change the result (the closest hit does not depend on the order in which leaves are visited).
+// Measured: with the scene in LDS the bookkeeping costs more instructions than the better lane utilisation saves
+// (7-10 % slower); with the scene in HBM, where a step is a memory round trip, it is 25-35 % faster.
 template <bool ANY, bool LDSS, bool COUNT, int OCT>
 __device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri, V3 o, V3 d, float eps, Hit& h, uint32_t& cN, uint32_t& cT) {
+  constexpr bool POSTPONE = !LDSS && !COUNT;
   h.t = PT_FLT_MAX; h.u = 0.0f; h.v = 0.0f; h.tri = 0xFFFFFFFFu;
   bool found = false;
   uint32_t stack[64];
   int sp = 0;
   uint32_t ref = sc.rootRef;
-  for (;;) {
-    while (isInternal(ref)) { if (COUNT) cN += 2; ref = stepDown<LDSS, OCT>(sc, ri, h.t, ref, stack, sp); }
-    if (ref == PT_NONE) break;
-    uint32_t cnt = ref >> BVH_COUNT_SHIFT, first = ref & BVH_INDEX_MASK;
-    for (uint32_t i = 0; i < cnt; i++) {
-      if (COUNT) cT += 1;
-      if (testTriangle<ANY, LDSS>(sc, (first + i) * 3, o, d, eps, h, found)) return true;
+  if constexpr (!POSTPONE) {
+    for (;;) {
+      while (isInternal(ref)) { if (COUNT) cN += 2; ref = stepDown<LDSS, OCT>(sc, ri, h.t, ref, stack, sp); }
+      if (ref == PT_NONE) break;
+      uint32_t cnt = ref >> BVH_COUNT_SHIFT, first = ref & BVH_INDEX_MASK;
+      for (uint32_t i = 0; i < cnt; i++) {
+        if (COUNT) cT += 1;
+        if (testTriangle<ANY, LDSS>(sc, (first + i) * 3, o, d, eps, h, found)) return true;
+      }
+      if (sp == 0) break;
+      ref = popRef(stack, sp);
     }
-    if (sp == 0) break;
-    ref = popRef(stack, sp);
+  } else {
+    uint32_t leaf = PT_NONE;
+    if (isLeaf(ref)) { leaf = ref; ref = PT_NONE; }                        // the root is a leaf
+    for (;;) {
+      while (isInternal(ref)) {
+        ref = stepDown<LDSS, OCT>(sc, ri, h.t, ref, stack, sp);
+        if (leaf == PT_NONE && isLeaf(ref)) { leaf = ref; ref = sp ? popRef(stack, sp) : PT_NONE; }
+        if (!__any(leaf == PT_NONE && ref != PT_NONE)) break;
+      }
+      while (leaf != PT_NONE) {
+        uint32_t cnt = leaf >> BVH_COUNT_SHIFT, first = leaf & BVH_INDEX_MASK;
+        for (uint32_t i = 0; i < cnt; i++)
+          if (testTriangle<ANY, LDSS>(sc, (first + i) * 3, o, d, eps, h, found)) return true;
+        leaf = PT_NONE;
+        if (isLeaf(ref)) { leaf = ref; ref = sp ? popRef(stack, sp) : PT_NONE; }
+      }
+      if (ref == PT_NONE) break;
+    }
   }
   return found;
 }
@@ -890,8 +886,6 @@ Geo traversalGeo(const LaunchCfg& lc, const DevScene& sc, uint64_t maxItems) {
   else if (sc.ldsBytes <= 78 * 1024) { bs = 1024; perCU = 2; }
   else { bs = 1024; perCU = 1; }
   uint64_t want = (maxItems + bs - 1) / bs;
-  static const char* envDiv = getenv("PTGPU_X_PER_CU_DIV");
-  if (envDiv) perCU = std::max(1u, perCU / (uint32_t)atoi(envDiv));
   uint64_t cap = (uint64_t)lc.numCUs * perCU;
   g.block = dim3(bs); g.grid = dim3((unsigned)std::max<uint64_t>(1, std::min(want, cap)));
   return g;
