@@ -60,13 +60,21 @@ def main():
 
     rank, world = multigpu.rank_world()
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # rehearsal of the N > 1 code path on a box with fewer GPUs than ranks: PT_BENCH_REHEARSAL=1 puts every rank on
+    # device 0 and combines over gloo instead of RCCL (which refuses two ranks on one device); never a measurement
+    rehearsal = os.environ.get('PT_BENCH_REHEARSAL') == '1'
+    if rehearsal:
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d' % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('no GPU visible: bench.py measures the HIP path only')
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if rehearsal:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     wl = dict(WORKLOADS[args.workload])
     spp = args.spp or wl['spp']
@@ -91,7 +99,12 @@ def main():
     def step():
         acc.zero_()
         multigpu.render_share(pt, spp, rank, world, split=args.split)
-        multigpu.combine(acc, dist if world > 1 else None, dst=0)
+        if rehearsal and world > 1:                 # gloo reduces host tensors only
+            host = acc.cpu()
+            multigpu.combine(host, dist, dst=0)
+            acc.copy_(host)
+        else:
+            multigpu.combine(acc, dist if world > 1 else None, dst=0)
 
     def fence():
         torch.cuda.synchronize()
@@ -126,8 +139,8 @@ def main():
     st = pt.stats()
 
     rays = float(total_rays(st)); samples = float(st.samples)
-    tvec = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-    rvec = torch.tensor([rays, samples], dtype=torch.float64, device='cuda')
+    tvec = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if rehearsal else 'cuda')
+    rvec = torch.tensor([rays, samples], dtype=torch.float64, device='cpu' if rehearsal else 'cuda')
     if world > 1:
         dist.all_reduce(tvec, op=dist.ReduceOp.MAX)
         dist.all_reduce(rvec, op=dist.ReduceOp.SUM)

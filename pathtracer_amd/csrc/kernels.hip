@@ -3,9 +3,10 @@
 // One sample of the reference's computeL (rendering.d:464-484) is split into stages that each run over a
 // whole batch of paths; the stages talk through structure-of-arrays queues in HBM:
 //
-//   raygen             getViewRay (rendering.d:278-285) + the part of Scene.trace that can be decided against the
-//                      scene's bounding box: rays that miss it take the `else` branch of computeL right away
-//                      (sampleSky, rendering.d:480); the rest are compacted into a ray queue
+//   raygen             getViewRay (rendering.d:278-285) + the part of Scene.trace that can be decided per pixel
+//                      (coverage mask of the triangles' screen rectangles, else the scene's bounding box): rays
+//                      that cannot hit take the `else` branch of computeL right away (sampleSky, rendering.d:480);
+//                      the rest are compacted into a ray queue
 //   extend             Scene.trace (scene.d:681-743) of a ray queue: view rays, later the indirect rays
 //   shade              computeL / computeLdirect / computeLindirect bodies between the trace calls
 //                                                           rendering.d:376-462, 472-481
@@ -17,7 +18,9 @@
 // a lane's rank inside its wave comes from a wave64 ballot + mbcnt, the wave's base from an LDS counter of its
 // workgroup, the workgroup's base is the fixed start of its segment -- no global atomic is on the data path (a
 // single 4-byte word sustains < 10^8 atomics/s, which at these ray rates is less than one per workgroup).
-// k_scan turns the per-segment counts into the prefix sums the next stage indexes with.
+// k_scan turns the per-segment counts into the prefix sums the next stage indexes with.  raygen and shade run as
+// PT_SEGS static block-tasks (uniform work per entry); the traversal kernels are persistent and hand a queue out
+// dynamically, 64 entries per wave at a time (WorkPool), because traversal times vary by an order of magnitude.
 //
 // Traversal: stack-based, near child first, over the BVH2 of bvh.h.  When the scene fits, nodes and
 // triangles are staged in LDS once per (persistent) workgroup; otherwise they are read from HBM/L2.

@@ -171,6 +171,26 @@ def test_background_with_the_sun_disc_in_view_is_bit_identical(require_gpu):
         assert st.raysPrimary == W * H * spp and st.raysCulled >= (bg.sum() * spp if flags == 0 else 0)
 
 
+def test_scene_without_hittable_triangles_renders_the_sky(require_gpu):
+    """Zero triangles, and triangles that can never be hit (degenerate: |det| < FloatEpsilon for every ray): every
+    sample takes computeL's else branch (rendering.d:480)."""
+    from conftest import UP
+    W, H, spp = 64, 40, 5
+    mats = np.array([[0.0, 0.7, 0.7, 0.7]], np.float32)
+    line = np.array([[[0, 0, 0], [1, 1, 1], [2, 2, 2]]], np.float32)          # collinear vertices
+    for v in (np.zeros((0, 3, 3), np.float32), line):
+        for flags in (0, P.PT_FLAG_NO_COVERAGE_MASK):
+            pt = P.PathTracer(W, H, device=0, has_sky=1, seed=1, flags=flags)
+            pt.upload_scene(v, np.zeros_like(v), np.zeros(len(v), np.uint32), mats)
+            pt.set_camera(oracle_py.camera_lookat(30.0, H / W, (5, 4, -3), (0, 0, 0), UP))    # looks down: no sun disc
+            pt.render_frame(spp)
+            px = pt.read_pixels()
+            assert (px['n'] == spp).all()
+            assert np.allclose(px['color'], np.array([0.682, 0.977, 1.0], np.float32), rtol=1e-6)
+            st = pt.stats()
+            assert st.raysOcclusion == 0 and st.raysPrimary == W * H * spp
+
+
 def test_band_and_sample_splits_reassemble_bit_identically(require_gpu):
     """Two handles stand in for two GPUs: interleaved 4-scanline bands summed == one GPU; sample slices summed ==
     the per-slice images added."""
