@@ -50,6 +50,7 @@ def main():
     ap.add_argument('--batch-slots', type=int, default=0)
     ap.add_argument('--max-leaf', type=int, default=0)
     ap.add_argument('--soup-tris', type=int, default=10_000_000, help='triangles of the synthetic soup workload')
+    ap.add_argument('--bvh', default='auto', choices=['auto', 'gpu', 'host'], help='where the BVH is built (auto: GPU from 1 M triangles)')
     args = ap.parse_args()
 
     import numpy as np
@@ -83,14 +84,15 @@ def main():
 
     acc = torch.zeros(W * H * 4, dtype=torch.float32, device='cuda')
     pt = P.PathTracer(W, H, device=local_rank, has_sky=wl['sky'], mode=wl['mode'], seed=0x5EED,
-                      batch_slots=args.batch_slots, max_leaf_tris=args.max_leaf)
+                      batch_slots=args.batch_slots, max_leaf_tris=args.max_leaf,
+                      flags={'auto': 0, 'gpu': P.PT_FLAG_GPU_BVH, 'host': P.PT_FLAG_HOST_BVH}[args.bvh])
     pt.set_stream(torch.cuda.current_stream().cuda_stream)
     pt.bind_accumulator(acc)
     if wl['model'] == 'soup':
         from pathtracer_amd.synthetic import soup
         t_b = time.perf_counter()
         pt.upload_scene(**soup(args.soup_tris))
-        print('soup: %d triangles, scene prepared (BVH build on the host) in %.1f s' % (args.soup_tris, time.perf_counter() - t_b),
+        print('soup: %d triangles, scene generated, BVH built and uploaded in %.1f s' % (args.soup_tris, time.perf_counter() - t_b),
               file=sys.stderr, flush=True)
     else:
         pt.Scene(model)
@@ -113,7 +115,8 @@ def main():
         torch.cuda.synchronize()
 
     # ---- traversal-cost pass (un-timed): mean box / triangle tests per ray of each kind, 1 spp ----
-    pt.set_config(flags=P.PT_FLAG_COUNT_VISITS)
+    bvh_flag = {'auto': 0, 'gpu': P.PT_FLAG_GPU_BVH, 'host': P.PT_FLAG_HOST_BVH}[args.bvh]
+    pt.set_config(flags=P.PT_FLAG_COUNT_VISITS | bvh_flag)
     pt.reset_stats()
     pt.render_frame(1); pt.synchronize()
     cst = pt.stats()
@@ -126,7 +129,7 @@ def main():
     bytes_any = B_STREAM_ANY + visits['nodes_any'] * B_NODE + visits['tris_any'] * B_TRI
 
     # ---- warm-up, then the timed region with every kernel launch bracketed by HIP events ----
-    pt.set_config(flags=P.PT_FLAG_TIME_KERNELS)
+    pt.set_config(flags=P.PT_FLAG_TIME_KERNELS | bvh_flag)
     for _ in range(args.warmup):
         step()
     fence()
@@ -192,7 +195,8 @@ def main():
             'config': {'workload': args.workload + ('' if not args.spp else ' (spp overridden to %d)' % spp),
                        'width': W, 'height': H, 'spp_per_gpu': spp, 'spp_total': spp * (world if args.split == 'samples' else 1),
                        'mode': wl['mode'], 'hasSky': wl['sky'], 'split': args.split, 'triangles': int(st.numTriangles),
-                       'bvh_nodes': int(st.numNodes)},
+                       'bvh_nodes': int(st.numNodes), 'bvh_built_on': 'gpu' if st.bvhOnGpu else 'host',
+                       'bvh_build_s': round(st.bvhBuildSeconds, 3)},
             'spp_per_s': round(samples / (W * H) / elapsed, 2), 'Msamples_per_s': round(samples / elapsed / 1e6, 2),
             'rays_per_sample': round(rays / max(1.0, samples), 4),
             'rays': {'primary': int(st.raysPrimary), 'primary_answered_in_raygen': int(st.raysCulled),

@@ -62,6 +62,9 @@ typedef struct PtConfig {
 #define PT_FLAG_TIME_KERNELS 4u   /* bracket every kernel launch with events (ptgpu_get_stats)         */
 #define PT_FLAG_NO_COVERAGE_MASK 8u /* cull view rays by the scene's bounding box only, not by the per-pixel
                                        screen-space coverage mask of the triangles                       */
+#define PT_FLAG_GPU_BVH 16u       /* build the BVH on the GPU (Morton-order LBVH) whatever the scene size;
+                                     default: on the GPU from 1 M triangles up, binned SAH on the host below */
+#define PT_FLAG_HOST_BVH 32u      /* always build the BVH on the host                                     */
 
 typedef struct PtMaterial { float emissive; float color[3]; } PtMaterial;        /* rendering.d:33-37 */
 typedef struct PtPixel { float color[3]; float n; float sum[3]; } PtPixel;        /* rendering.d:24-30 */
@@ -84,7 +87,8 @@ typedef struct PtStats {
   double renderMs;           /* event time first kernel -> last kernel of all ptgpu_render calls          */
   uint32_t numTriangles, numNodes, bvhDepth, numLightGroups;
   uint32_t sceneInLds;       /* 1 if nodes + triangles are staged in LDS by the traversal kernels         */
-  uint32_t reserved;
+  uint32_t bvhOnGpu;         /* 1 if the BVH of the current scene was built on the GPU                    */
+  double bvhBuildSeconds;    /* wall time of that build (host or GPU, transfers included)                 */
 } PtStats;
 
 const char* ptgpu_last_error(void);

@@ -142,6 +142,79 @@ def test_soup_scene_from_global_memory(require_gpu):
     assert np.array_equal(pt.hitsNothing(rays), o.trace_rays(rays, kind=1)[0] < 0)
 
 
+def check_tree(nodes, order, num_tris, v, max_leaf):
+    """Structure of a flattened BVH (layout of bvh.h): every hittable triangle in exactly one leaf, every box
+    contains what hangs below it, leaves within the size bound.  Returns (depth, number of leaves)."""
+    refs = nodes[:, 3].view(np.uint32)
+    seen = np.zeros(len(order), np.int32)
+    vv = v.reshape(-1, 3, 3)
+    stack = [(0, 1)]
+    depth = leaves = 0
+    while stack:
+        node, d = stack.pop()
+        depth = max(depth, d)
+        ref = int(refs[node]); cnt, idx = ref >> 28, ref & ((1 << 28) - 1)
+        mn, mx = nodes[node, 0:3], nodes[node, 4:7]
+        if cnt == 0:
+            for c in (2 * idx, 2 * idx + 1):
+                assert (nodes[c, 0:3] >= mn - 1e-6).all() and (nodes[c, 4:7] <= mx + 1e-6).all()
+                stack.append((c, d + 1))
+        else:
+            assert cnt <= max_leaf
+            leaves += 1
+            seen[idx:idx + cnt] += 1
+            tri = vv[order[idx:idx + cnt]]
+            assert (tri.min((0, 1)) >= mn).all() and (tri.max((0, 1)) <= mx).all()
+    assert (seen == 1).all() and len(order) == num_tris
+    return depth, leaves
+
+
+def test_bvh_built_on_the_gpu(require_gpu, flats):
+    """PT_FLAG_GPU_BVH (the default from 1 M triangles up): Morton-order LBVH built by HIP kernels.  The tree is a
+    valid BVH in the layout the traversal kernels read, and -- the closest hit being independent of the tree -- view
+    rays, random rays and a rendered image are the same bits as with the SAH tree built on the host."""
+    fl = soup(200000, seed=0x5EED)
+    W, H = 96, 54
+    cam = P.Camera(30.0, H / W).setTransform((250, 180, 160), (0, 0, 0), (0, 0, 1))
+    tr = []
+    for flags in (P.PT_FLAG_GPU_BVH, P.PT_FLAG_HOST_BVH):
+        pt = P.PathTracer(W, H, has_sky=1, seed=9, flags=flags)
+        pt.upload_scene(fl['v'], fl['n'], fl['mat_idx'], fl['materials'])
+        pt.set_camera(cam)
+        tr.append(pt)
+    g, h = tr
+    assert g.stats().bvhOnGpu == 1 and h.stats().bvhOnGpu == 0
+    nodes, order = g.get_bvh()
+    depth, leaves = check_tree(nodes.reshape(-1, 8), order, len(fl['v']), fl['v'], 4)
+    assert depth - 1 == g.stats().bvhDepth <= 60 and leaves > len(order) / 4          # bvhDepth counts edges, the root is 0
+    for x, y in zip(g.trace_primary(), h.trace_primary()):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    rays = random_rays(fl, 20000, 7)
+    for x, y in zip(g.trace(rays)[:4], h.trace(rays)[:4]):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    assert np.array_equal(g.hitsNothing(rays), h.hitsNothing(rays))
+    g.render_frame(4); h.render_frame(4)
+    assert np.array_equal(g.read_pixels()['sum'].view(np.uint32), h.read_pixels()['sum'].view(np.uint32))
+    # a scene with duplicate centroids and degenerate / NaN triangles among the hittable ones
+    v = np.concatenate([fl['v'][:3000], fl['v'][:3000], np.zeros((50, 3, 3), np.float32),
+                        np.full((5, 3, 3), np.nan, np.float32)]).astype(np.float32)
+    t2 = P.PathTracer(W, H, flags=P.PT_FLAG_GPU_BVH)
+    t2.upload_scene(v, np.zeros_like(v), np.zeros(len(v), np.uint32), fl['materials'])
+    t2.set_camera(cam)
+    assert t2.stats().bvhOnGpu == 1
+    nodes, order = t2.get_bvh()
+    check_tree(nodes.reshape(-1, 8), order[:6000], 6000, v, 4)          # the 55 triangles that cannot be hit are left out
+    o = oracle_py.Oracle({'v': v, 'n': np.zeros_like(v), 'mat_idx': np.zeros(len(v), np.uint32), 'materials': fl['materials']},
+                         build_tree=False)
+    r2 = random_rays({'v': v[:6000]}, 4000, 3)
+    tri, t, u, vv, _ = t2.trace(r2)
+    assert_hits_equal((tri, t, u, vv), o.trace_rays(r2, kind=0))
+    # the shipped teapot through the GPU builder
+    a = make_tracer('teapot', 256, 144, flags=P.PT_FLAG_GPU_BVH)
+    assert a.stats().bvhOnGpu == 1
+    assert_hits_equal(a.trace_primary(), make_oracle(flats['teapot'], 'teapot', 256, 144).trace_primary(0, 256 * 144, use_tree=False))
+
+
 def test_degenerate_inputs(require_gpu):
     mats = np.array([[0, .7, .7, .7]], np.float32)
     pt = P.PathTracer(32, 32)
