@@ -148,6 +148,17 @@ int ptgpu_tonemap(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount, uint8_
  * Outputs may be NULL.  triId = -1 and t = FLT_MAX on a miss. */
 int ptgpu_scene_trace(PtHandle* h, const float* rays6, uint32_t count, int32_t* triId, float* t, float* u, float* v,
                       float* normal3);
+/* Scene.trace, texcoord variant (scene.d:745-796): closest hit of caller-supplied rays on either side of the
+ * surface, or front faces only when ignoreBackfaces != 0 (IgnoreBackfaces, scene.d:62-66).  result[i] is TraceResult
+ * (scene.d:55-60): 0 FrontFaceHit, 1 BackFaceHit, 2 NoHit.  tc2 = 2 floats per ray, TriangleData.tex interpolated by
+ * interpolate() (scene.d:68-105); (0, 0) on a miss.  triId / t as for ptgpu_scene_trace.  triId, t, tc2 may be NULL. */
+int ptgpu_scene_trace_tex(PtHandle* h, const float* rays6, uint32_t count, int ignoreBackfaces, int32_t* result,
+                          int32_t* triId, float* t, float* tc2);
+/* TriangleData.tex (scene.d:305-307) of the current scene: numTriangles x 3 x (s, t) in triangle input order.
+ * ptgpu_load_thmodel fills it from the file (texcoord set 1 as the reference indexes it; the last set present when
+ * the mesh has fewer; zeros when it has none); ptgpu_upload_scene leaves it zero.  set replaces it. */
+int ptgpu_set_texcoords(PtHandle* h, const float* tex6);
+int ptgpu_get_texcoords(PtHandle* h, float* tex6);
 /* Scene.hitsNothing (scene.d:801-838): out[i] = 1 if ray i hits no geometry. */
 int ptgpu_scene_hits_nothing(PtHandle* h, const float* rays6, uint32_t count, uint8_t* out);
 /* Parity probe: getViewRay without jitter (rendering.d:278-285) + Scene.trace for a pixel window. */

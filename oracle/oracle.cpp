@@ -24,6 +24,7 @@
 //   computeOutputColor   rendering.d:494-500
 //   sphere tree build    scene.d:589-609, 353-500, linearizeNodes scene.d:1089-1150
 //   Scene.trace          scene.d:681-743      Scene.hitsNothing scene.d:801-838
+//   Scene.trace (texcoord variant) scene.d:745-796, interpolate scene.d:68-105 (exhaustive form only)
 //   bands + per-band RNG main.d:117,184-192   tone map main.d:82-95
 //
 // Chosen semantics (thBase is absent):
@@ -82,7 +83,7 @@ inline V3 mat3cols(V3 c0, V3 c1, V3 c2, V3 v) {                                 
 
 struct Ray { V3 o, d; };
 struct Tri { V3 v0, v1, v2; };
-struct TriData { V3 n[3]; uint32_t mat; };
+struct TriData { V3 n[3]; uint32_t mat; float tex[3][2] = {{0, 0}, {0, 0}, {0, 0}}; };
 struct Material { float emissive; V3 color; };
 struct LightTri { V3 v0, e1, e2; float area, probability; };   // rendering.d:40-46
 struct Pixel { float color[3]; float n; float sum[3]; };        // rendering.d:24-30
@@ -353,6 +354,43 @@ struct Scene {
       float pos = -1.0f, u = 0, v = 0, det; cn.tris++;
       if (triIntersects(tris[i], ray, eps, pos, u, v, det) && pos < rayPos && pos >= eps && det < 0.0f) {
         rayPos = pos; h.t = pos; h.u = u; h.v = v; h.tri = (int)i; result = true;
+      }
+    }
+    return result;
+  }
+  // interpolate(u, v, val0, val1, val2) for one float component, scene.d:68-105
+  static float interpolate1(float u, float v, float val0, float val1, float val2) {
+    if (u < 0.0f) u = 0.0f;
+    if (v < 0.0f) v = 0.0f;
+    float uv = (u + v);
+    float u1, v1;
+    if (uv != 0.0f) { float x = 1.0f / uv; u1 = x * u; v1 = x * v; }
+    else { u1 = u; v1 = v; }
+    const float sqrt2 = 1.414213562f;
+    float d1 = sqrtf((1.0f - u1) * (1.0f - u1) + v1 * v1) / sqrt2;
+    float d2 = sqrtf(u1 * u1 + (1.0f - v1) * (1.0f - v1)) / sqrt2;
+    float interpolated1 = val1 * d1 + val2 * d2;
+    float i1;
+    if (uv != 0.0f) { float len = sqrtf(u1 * u1 + v1 * v1); i1 = sqrtf(u * u + v * v) / len; }
+    else i1 = 0.0f;
+    float i2 = 1.0f - i1;
+    return val0 * i2 + interpolated1 * i1;
+  }
+  // Scene.trace, texcoord variant (scene.d:745-796) over ALL triangles; ties keep the lowest triangle index.
+  // Returns TraceResult: 0 FrontFaceHit, 1 BackFaceHit, 2 NoHit (scene.d:55-60).
+  int traceTexBrute(const Ray& ray, bool ignoreBackfaces, float& rayPos, float tc[2], int& tri) const {
+    rayPos = FLT_MAX; int result = 2; tri = -1; tc[0] = tc[1] = 0.0f; float eps = cfg.floatEpsilon;
+    for (size_t i = 0; i < tris.size(); i++) {
+      float pos = -1.0f, u = 0, v = 0, det;
+      if (triIntersects(tris[i], ray, eps, pos, u, v, det) && pos < rayPos && pos >= eps) {
+        bool isFrontFace = det < 0.0f;                                   // S6
+        if (!ignoreBackfaces || isFrontFace) {
+          rayPos = pos; tri = (int)i;
+          const TriData& ld = data[i];
+          tc[0] = interpolate1(u, v, ld.tex[0][0], ld.tex[1][0], ld.tex[2][0]);
+          tc[1] = interpolate1(u, v, ld.tex[0][1], ld.tex[1][1], ld.tex[2][1]);
+          result = isFrontFace ? 0 : 1;
+        }
       }
     }
     return result;
@@ -661,6 +699,21 @@ void orc_trace_rays(void* h, const float* rays6, uint32_t count, int kind, int u
     } else {
       triId[i] = tr.hitsNothing(r) ? -1 : 0;
     }
+  }
+}
+// Texture coordinates per triangle vertex (scene.d:305-307): tex6 = T x 3 x (s, t)
+void orc_set_texcoords(void* h, const float* tex6) {
+  Scene* s = (Scene*)h;
+  for (size_t i = 0; i < s->data.size(); i++)
+    for (int k = 0; k < 3; k++) { s->data[i].tex[k][0] = tex6[6 * i + 2 * k]; s->data[i].tex[k][1] = tex6[6 * i + 2 * k + 1]; }
+}
+// Scene.trace, texcoord variant: result = TraceResult (0 front, 1 back, 2 none), tc2 = interpolated texcoords
+void orc_trace_tex(void* h, const float* rays6, uint32_t count, int ignoreBackfaces, int32_t* result, int32_t* triId, float* t,
+                   float* tc2) {
+  Scene* s = (Scene*)h;
+  for (uint32_t i = 0; i < count; i++) {
+    const float* p = rays6 + 6 * i; Ray r{v3(p[0], p[1], p[2]), v3(p[3], p[4], p[5])};
+    int tri; result[i] = s->traceTexBrute(r, ignoreBackfaces != 0, t[i], tc2 + 2 * i, tri); triId[i] = tri;
   }
 }
 void orc_interp_normal(void* h, uint32_t tri, float u, float v, float* out3) {

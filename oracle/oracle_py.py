@@ -47,6 +47,8 @@ def lib():
         L.orc_view_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int] + [C.c_void_p] * 4
         L.orc_interp_normal.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_void_p]
+        L.orc_set_texcoords.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_trace_tex.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int] + [C.c_void_p] * 4
         L.orc_render_mt.restype = C.c_double
         L.orc_render_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_render_keyed.restype = C.c_double
@@ -83,6 +85,9 @@ class Oracle:
         self.h = lib().orc_create(_p(self.v), _p(self.nrm), _p(self.mi), _p(self.mats), self.T, self.M, int(build_tree))
         self.cfg = OrcConfig()
         self.has_tree = bool(build_tree)
+        if flat.get('tex') is not None:
+            self.tex = np.ascontiguousarray(flat['tex'], np.float32).reshape(-1, 6)
+            lib().orc_set_texcoords(self.h, _p(self.tex))
         self.configure()
 
     def close(self):
@@ -130,6 +135,13 @@ class Oracle:
         tri = np.empty(n, np.int32); t = np.empty(n, np.float32); u = np.empty(n, np.float32); v = np.empty(n, np.float32)
         lib().orc_trace_rays(self.h, _p(rays6), n, kind, int(use_tree), _p(tri), _p(t), _p(u), _p(v))
         return tri, t, u, v
+
+    def trace_tex(self, rays6, ignore_backfaces=True):
+        """Scene.trace, texcoord variant (scene.d:745-796): result (0 front, 1 back, 2 none), triangle, t, texcoords."""
+        rays6 = np.ascontiguousarray(rays6, np.float32); n = len(rays6)
+        res = np.empty(n, np.int32); tri = np.empty(n, np.int32); t = np.empty(n, np.float32); tc = np.empty((n, 2), np.float32)
+        lib().orc_trace_tex(self.h, _p(rays6), n, int(ignore_backfaces), _p(res), _p(tri), _p(t), _p(tc))
+        return res, tri, t, tc
 
     def interp_normal(self, tri, u, v):
         out = np.empty(3, np.float32)

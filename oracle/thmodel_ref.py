@@ -256,7 +256,7 @@ def flatten(model, model_matrix=None, mat_func=fill_material):
     if not leafs:
         raise ValueError('no leaf nodes found')
     mats = np.stack([mat_func(m['name']) for m in model['materials']])   # scene.d:239-245
-    V, N, MI = [], [], []
+    V, N, MI, TX = [], [], [], []
     for leaf in leafs:
         tr = mat4_mul(root['transform'], model_matrix)      # scene.d:257
         cur = leaf
@@ -275,9 +275,14 @@ def flatten(model, model_matrix=None, mat_func=fill_material):
             f = mesh['faces']
             V.append(vt[f]); N.append(nt[f])
             MI.append(np.full(len(f), mesh['materialIndex'], np.uint32))
+            # scene.d:305-307 reads texcoord set 1; the shipped models only carry set 0 (the D program would stop
+            # with a range error on them), so the last set present stands in, zeros if there is none
+            tcs = mesh['texcoords']
+            tc = tcs[1] if len(tcs) > 1 else (tcs[0] if tcs else np.zeros((len(mesh['vertices']), 2), F32))
+            TX.append(tc.astype(F32)[f])
     return {'v': np.concatenate(V).astype(F32), 'n': np.concatenate(N).astype(F32),
             'mat_idx': np.concatenate(MI), 'materials': mats.astype(F32),
-            'names': [m['name'] for m in model['materials']]}
+            'names': [m['name'] for m in model['materials']], 'tex': np.concatenate(TX).astype(F32)}
 
 
 def load_flat(path, raw_mesh_space=True):

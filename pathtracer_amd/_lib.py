@@ -53,6 +53,9 @@ SYMBOLS = {
     'ptgpu_clear_pixels': (_I, [_VP]),
     'ptgpu_tonemap': (_I, [_VP, _U32, _U32, _VP]),
     'ptgpu_scene_trace': (_I, [_VP, _VP, _U32, _VP, _VP, _VP, _VP, _VP]),
+    'ptgpu_scene_trace_tex': (_I, [_VP, _VP, _U32, _I, _VP, _VP, _VP, _VP]),
+    'ptgpu_set_texcoords': (_I, [_VP, _VP]),
+    'ptgpu_get_texcoords': (_I, [_VP, _VP]),
     'ptgpu_scene_hits_nothing': (_I, [_VP, _VP, _U32, _VP]),
     'ptgpu_trace_primary': (_I, [_VP, _U32, _U32, _VP, _VP, _VP, _VP]),
     'ptgpu_view_rays': (_I, [_VP, _U32, _U32, _VP]),

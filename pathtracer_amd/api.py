@@ -210,6 +210,29 @@ class PathTracer:
         self._check(self.lib.ptgpu_scene_trace(self.h, _ptr(rays6), n, _ptr(tri), _ptr(t), _ptr(u), _ptr(v), _ptr(nrm)))
         return tri, t, u, v, nrm
 
+    def trace_tex(self, rays6, ignore_backfaces=True):
+        """Scene.trace(ray, rayPos, texcoords, data, ignoreBackfaces) (scene.d:745-796) ->
+        (TraceResult 0 front / 1 back / 2 none, triangle id, rayPos, texcoords)."""
+        rays6 = np.ascontiguousarray(rays6, np.float32).reshape(-1, 6); n = len(rays6)
+        res = np.zeros(n, np.int32); tri = np.zeros(n, np.int32); t = np.zeros(n, np.float32)
+        tc = np.zeros((n, 2), np.float32)
+        self._check(self.lib.ptgpu_scene_trace_tex(self.h, _ptr(rays6), n, 1 if ignore_backfaces else 0, _ptr(res),
+                                                   _ptr(tri), _ptr(t), _ptr(tc)))
+        return res, tri, t, tc
+
+    def set_texcoords(self, tex):
+        """TriangleData.tex (scene.d:305-307): T x 3 x (s, t) in triangle input order."""
+        tex = np.ascontiguousarray(tex, np.float32).reshape(-1, 6)
+        if len(tex) != self.stats().numTriangles:
+            raise ValueError('tex must hold 3 x 2 floats for every triangle of the scene')
+        self._check(self.lib.ptgpu_set_texcoords(self.h, _ptr(tex)))
+        return self
+
+    def get_texcoords(self):
+        tex = np.zeros((max(1, self.stats().numTriangles), 6), np.float32)
+        self._check(self.lib.ptgpu_get_texcoords(self.h, _ptr(tex)))
+        return tex[:self.stats().numTriangles].reshape(-1, 3, 2)
+
     def hitsNothing(self, rays6):
         rays6 = np.ascontiguousarray(rays6, np.float32).reshape(-1, 6); n = len(rays6)
         out = np.zeros(n, np.uint8)

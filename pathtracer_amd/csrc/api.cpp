@@ -63,6 +63,7 @@ struct PtHandle {
   SceneBox box{};
   // coverage mask of the view rays (scene_host.h: buildCoverageMask); rebuilt when the scene or the camera changes
   DevBuf dMask, dSkyMask; bool maskDirty = true, maskUsable = false;
+  DevBuf dTex; bool texDirty = true;   // TriangleData.tex in input order, uploaded at the first texcoord trace
   ViewMasks masks() const { return maskUsable ? ViewMasks{dMask.as<uint32_t>(), dSkyMask.as<uint32_t>()} : ViewMasks{nullptr, nullptr}; }
   DevBuf bMetaDesc; std::vector<QMeta> metas;     // queue descriptors: device copy and host copy, stage-major
   Wavefront wf{}; uint32_t wfKinds = 0, wfRounds = 0;
@@ -202,7 +203,7 @@ void uploadScene(PtHandle* h) {
 
   h->st.numTriangles = T; h->st.numNodes = bvh.numNodes; h->st.bvhDepth = bvh.depth;
   h->st.numLightGroups = (uint32_t)lt.numGroups();
-  h->maskDirty = true;
+  h->maskDirty = true; h->texDirty = true;
   if (h->cfg.device < 0) { h->haveScene = true; return; }
   auto up = [&](DevBuf& b, const void* src, size_t bytes) {
     b.alloc(bytes);
@@ -652,6 +653,56 @@ int ptgpu_scene_trace(PtHandle* h, const float* rays6, uint32_t count, int32_t* 
     if (u) HIPCHECK(hipMemcpyAsync(u, du.p, (size_t)count * 4, hipMemcpyDeviceToHost, h->stream));
     if (v) HIPCHECK(hipMemcpyAsync(v, dv.p, (size_t)count * 4, hipMemcpyDeviceToHost, h->stream));
     if (normal3) HIPCHECK(hipMemcpyAsync(normal3, dn.p, (size_t)count * 12, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+  });
+}
+
+int ptgpu_set_texcoords(PtHandle* h, const float* tex6) {
+  return guarded([&]() {
+    if (!h) fail(PT_E_INVALID, "null handle");
+    if (!h->haveScene) fail(PT_E_STATE, "no scene");
+    size_t T = h->flat.numTriangles();
+    if (!tex6 && T) fail(PT_E_INVALID, "null argument");
+    h->flat.tex.assign(tex6, tex6 + T * 6);
+    h->texDirty = true;
+  });
+}
+
+int ptgpu_get_texcoords(PtHandle* h, float* tex6) {
+  return guarded([&]() {
+    if (!h || !tex6) fail(PT_E_INVALID, "null argument");
+    if (!h->haveScene) fail(PT_E_STATE, "no scene");
+    size_t T = h->flat.numTriangles();
+    if (h->flat.tex.size() == T * 6) std::memcpy(tex6, h->flat.tex.data(), T * 24);
+    else std::memset(tex6, 0, T * 24);
+  });
+}
+
+int ptgpu_scene_trace_tex(PtHandle* h, const float* rays6, uint32_t count, int ignoreBackfaces, int32_t* result, int32_t* triId,
+                          float* t, float* tc2) {
+  return guarded([&]() {
+    if (!h || ((!rays6 || !result) && count)) fail(PT_E_INVALID, "null argument");
+    if (!h->haveScene) fail(PT_E_STATE, "no scene");
+    useDevice(h);
+    if (!count) return;
+    size_t T = h->flat.numTriangles();
+    if (h->texDirty) {
+      h->dTex.alloc(std::max<size_t>(T, 1) * 24);
+      if (h->flat.tex.size() == T * 6 && T) HIPCHECK(hipMemcpy(h->dTex.p, h->flat.tex.data(), T * 24, hipMemcpyHostToDevice));
+      else HIPCHECK(hipMemset(h->dTex.p, 0, std::max<size_t>(T, 1) * 24));
+      h->texDirty = false;
+    }
+    DevBuf dr, dres, dtri, dt, dtc;
+    dr.alloc((size_t)count * 24); dres.alloc((size_t)count * 4); dtri.alloc((size_t)count * 4); dt.alloc((size_t)count * 4);
+    dtc.alloc((size_t)count * 8);
+    HIPCHECK(hipMemcpyAsync(dr.p, rays6, (size_t)count * 24, hipMemcpyHostToDevice, h->stream));
+    launchTraceTex(makeLaunchCfg(h), h->dsc, makeDevCfg(h), h->dTex.as<float>(), dr.as<float>(), count, ignoreBackfaces != 0,
+                   dres.as<int32_t>(), dtri.as<int32_t>(), dt.as<float>(), dtc.as<float>());
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(result, dres.p, (size_t)count * 4, hipMemcpyDeviceToHost, h->stream));
+    if (triId) HIPCHECK(hipMemcpyAsync(triId, dtri.p, (size_t)count * 4, hipMemcpyDeviceToHost, h->stream));
+    if (t) HIPCHECK(hipMemcpyAsync(t, dt.p, (size_t)count * 4, hipMemcpyDeviceToHost, h->stream));
+    if (tc2) HIPCHECK(hipMemcpyAsync(tc2, dtc.p, (size_t)count * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
   });
 }

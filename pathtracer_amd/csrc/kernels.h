@@ -166,6 +166,8 @@ void launchExtendPrimary(const LaunchCfg& lc, const DevScene& sc, const DevCfg& 
 void launchViewRays(const LaunchCfg& lc, const DevCfg& cfg, uint32_t pixelOffset, uint32_t count, float* rays6);
 void launchTraceRays(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const float* rays6, uint32_t count,
                      int32_t* triId, float* t, float* u, float* v, float* normal3);
+void launchTraceTex(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const float* tex6, const float* rays6,
+                    uint32_t count, bool ignoreBackfaces, int32_t* result, int32_t* triId, float* t, float* tc2);
 void launchHitsNothing(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const float* rays6, uint32_t count,
                        uint8_t* out);
 void launchTonemap(const LaunchCfg& lc, const float4* acc, uint32_t pixelOffset, uint32_t count, uint8_t* rgb);

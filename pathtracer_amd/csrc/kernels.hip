@@ -106,7 +106,7 @@ __device__ __forceinline__ bool slab(const RayInv& r, float mnx, float mny, floa
   return tn <= fminf(tf, tmax);
 }
 
-struct Hit { float t, u, v; uint32_t tri; };
+struct Hit { float t, u, v; uint32_t tri; bool front; };
 
 // Workgroup sizes of the kernels that run as PT_SEGS static block-tasks.
 #ifndef PT_RAYGEN_THREADS
@@ -125,7 +125,9 @@ struct Hit { float t, u, v; uint32_t tri; };
 // ANY: returns true when the hit is accepted (Scene.hitsNothing stops there).  Otherwise updates the closest
 // front-face hit and returns false.  (A straight-line form with one combined predicate instead of the nested
 // rejections was measured: the vector work of rejected triangles outweighs the exec-mask regions it removes.)
-template <bool ANY, bool LDSS>
+// BOTH (closest hit only): back faces are accepted too and h.front tells which side was hit -- the texcoord
+// variant of Scene.trace called with IgnoreBackfaces.no (scene.d:767-779).
+template <bool ANY, bool LDSS, bool BOTH = false>
 __device__ __forceinline__ bool testTriangle(const DevScene& sc, uint32_t row, V3 o, V3 d, float eps, Hit& h, bool& found) {
   float4 t0 = ldTri<LDSS>(sc, row), tA = ldTri<LDSS>(sc, row + 1), tB = ldTri<LDSS>(sc, row + 2);
   keepW<LDSS>(tA, tB); keepW<LDSS>(t0, t0);
@@ -146,8 +148,9 @@ __device__ __forceinline__ bool testTriangle(const DevScene& sc, uint32_t row, V
           if (t >= eps) { h.t = t; h.u = u; h.v = v; h.tri = orig; return true; }
         } else {
           // pos < rayPos && pos >= FloatEpsilon, then front face; equal t keeps the lower triangle id
-          if ((t < h.t || (t == h.t && orig < h.tri)) && t >= eps && det < 0.0f) {
+          if ((t < h.t || (t == h.t && orig < h.tri)) && t >= eps && (BOTH || det < 0.0f)) {
             h.t = t; h.u = u; h.v = v; h.tri = orig; found = true;
+            if (BOTH) h.front = det < 0.0f;
           }
         }
       }
@@ -201,10 +204,10 @@ __device__ __forceinline__ bool isLeaf(uint32_t ref) { return (ref >> BVH_COUNT_
 // ray do not change the result (the closest hit does not depend on the order in which leaves are visited).
 // Measured: with the scene in LDS the bookkeeping costs more instructions than the better lane utilisation saves
 // (7-10 % slower); with the scene in HBM, where a step is a memory round trip, it is 25-35 % faster.
-template <bool ANY, bool LDSS, bool COUNT, int OCT>
+template <bool ANY, bool LDSS, bool COUNT, int OCT, bool BOTH = false>
 __device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri, V3 o, V3 d, float eps, Hit& h, uint32_t& cN, uint32_t& cT) {
   constexpr bool POSTPONE = !LDSS && !COUNT;
-  h.t = PT_FLT_MAX; h.u = 0.0f; h.v = 0.0f; h.tri = 0xFFFFFFFFu;
+  h.t = PT_FLT_MAX; h.u = 0.0f; h.v = 0.0f; h.tri = 0xFFFFFFFFu; h.front = true;
   bool found = false;
   uint32_t stack[64];
   int sp = 0;
@@ -216,7 +219,7 @@ __device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri
       uint32_t cnt = ref >> BVH_COUNT_SHIFT, first = ref & BVH_INDEX_MASK;
       for (uint32_t i = 0; i < cnt; i++) {
         if (COUNT) cT += 1;
-        if (testTriangle<ANY, LDSS>(sc, (first + i) * 3, o, d, eps, h, found)) return true;
+        if (testTriangle<ANY, LDSS, BOTH>(sc, (first + i) * 3, o, d, eps, h, found)) return true;
       }
       if (sp == 0) break;
       ref = popRef(stack, sp);
@@ -233,7 +236,7 @@ __device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri
       while (leaf != PT_NONE) {
         uint32_t cnt = leaf >> BVH_COUNT_SHIFT, first = leaf & BVH_INDEX_MASK;
         for (uint32_t i = 0; i < cnt; i++)
-          if (testTriangle<ANY, LDSS>(sc, (first + i) * 3, o, d, eps, h, found)) return true;
+          if (testTriangle<ANY, LDSS, BOTH>(sc, (first + i) * 3, o, d, eps, h, found)) return true;
         leaf = PT_NONE;
         if (isLeaf(ref)) { leaf = ref; ref = sp ? popRef(stack, sp) : PT_NONE; }
       }
@@ -247,25 +250,25 @@ __device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri
 // octant (view rays of a pixel tile), the variant compiled for that octant runs (measured: 5 % on the view-ray
 // launch; nothing for any-hit queries, which therefore keep one variant).  Otherwise, and for the counting and
 // stand-alone variants, the general one.  Must be called with the lanes that have a ray active and no others.
-template <bool ANY, bool LDSS, bool COUNT, bool BY_OCTANT = !COUNT && !ANY>
+template <bool ANY, bool LDSS, bool COUNT, bool BY_OCTANT = !COUNT && !ANY, bool BOTH = false>
 __device__ __forceinline__ bool traverse(const DevScene& sc, V3 o, V3 d, float eps, Hit& h, uint32_t& cN, uint32_t& cT) {
   RayInv ri = makeRayInv(o, d);
   if constexpr (BY_OCTANT) {
     uint32_t oct = octantOf(ri), o0 = __builtin_amdgcn_readfirstlane(oct);
     if (__all(oct == o0)) {
       switch (o0) {
-        case 0: return traverseOct<ANY, LDSS, COUNT, 0>(sc, ri, o, d, eps, h, cN, cT);
-        case 1: return traverseOct<ANY, LDSS, COUNT, 1>(sc, ri, o, d, eps, h, cN, cT);
-        case 2: return traverseOct<ANY, LDSS, COUNT, 2>(sc, ri, o, d, eps, h, cN, cT);
-        case 3: return traverseOct<ANY, LDSS, COUNT, 3>(sc, ri, o, d, eps, h, cN, cT);
-        case 4: return traverseOct<ANY, LDSS, COUNT, 4>(sc, ri, o, d, eps, h, cN, cT);
-        case 5: return traverseOct<ANY, LDSS, COUNT, 5>(sc, ri, o, d, eps, h, cN, cT);
-        case 6: return traverseOct<ANY, LDSS, COUNT, 6>(sc, ri, o, d, eps, h, cN, cT);
-        default: return traverseOct<ANY, LDSS, COUNT, 7>(sc, ri, o, d, eps, h, cN, cT);
+        case 0: return traverseOct<ANY, LDSS, COUNT, 0, BOTH>(sc, ri, o, d, eps, h, cN, cT);
+        case 1: return traverseOct<ANY, LDSS, COUNT, 1, BOTH>(sc, ri, o, d, eps, h, cN, cT);
+        case 2: return traverseOct<ANY, LDSS, COUNT, 2, BOTH>(sc, ri, o, d, eps, h, cN, cT);
+        case 3: return traverseOct<ANY, LDSS, COUNT, 3, BOTH>(sc, ri, o, d, eps, h, cN, cT);
+        case 4: return traverseOct<ANY, LDSS, COUNT, 4, BOTH>(sc, ri, o, d, eps, h, cN, cT);
+        case 5: return traverseOct<ANY, LDSS, COUNT, 5, BOTH>(sc, ri, o, d, eps, h, cN, cT);
+        case 6: return traverseOct<ANY, LDSS, COUNT, 6, BOTH>(sc, ri, o, d, eps, h, cN, cT);
+        default: return traverseOct<ANY, LDSS, COUNT, 7, BOTH>(sc, ri, o, d, eps, h, cN, cT);
       }
     }
   }
-  return traverseOct<ANY, LDSS, COUNT, -1>(sc, ri, o, d, eps, h, cN, cT);
+  return traverseOct<ANY, LDSS, COUNT, -1, BOTH>(sc, ri, o, d, eps, h, cN, cT);
 }
 
 template <bool COUNT> __device__ __forceinline__ void flushCounts(unsigned long long* stats, int nodeSlot, uint32_t cN, uint32_t cT) {
@@ -841,6 +844,35 @@ __global__ void PT_TRAVERSAL_BOUNDS k_trace_rays(DevScene sc, float eps, const f
   }
 }
 
+// Scene.trace, texcoord variant (scene.d:745-796): closest hit on either side of the surface unless the caller
+// ignores back faces; reports TraceResult (scene.d:55-60: 0 FrontFaceHit, 1 BackFaceHit, 2 NoHit), the distance
+// and the texture coordinates interpolated with scene.d:68-105.  tex6 holds three (s, t) pairs per triangle in
+// input order.
+template <bool LDSS, bool BOTH>
+__global__ void PT_TRAVERSAL_BOUNDS k_trace_tex(DevScene sc, float eps, const float* __restrict__ tex6,
+                                                    const float* __restrict__ rays6, uint32_t count, int32_t* result,
+                                                    int32_t* triId, float* t, float* tc2) {
+  stageScene<LDSS>(sc);
+  uint32_t cN = 0, cT = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    const float* r = rays6 + 6 * (size_t)i;
+    Hit h;
+    bool ok = traverse<false, LDSS, false, false, BOTH>(sc, v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]), eps, h, cN, cT);
+    result[i] = ok ? (h.front ? 0 : 1) : 2;
+    if (triId) triId[i] = ok ? (int32_t)h.tri : -1;
+    if (t) t[i] = h.t;
+    if (tc2) {
+      float s = 0.0f, tt = 0.0f;
+      if (ok) {
+        const float* q = tex6 + 6 * (size_t)h.tri;
+        s = interpolateComponent(h.u, h.v, q[0], q[2], q[4]);
+        tt = interpolateComponent(h.u, h.v, q[1], q[3], q[5]);
+      }
+      tc2[2 * (size_t)i] = s; tc2[2 * (size_t)i + 1] = tt;
+    }
+  }
+}
+
 template <bool LDSS>
 __global__ void PT_TRAVERSAL_BOUNDS k_hits_nothing(DevScene sc, float eps, const float* __restrict__ rays6, uint32_t count,
                                                        uint8_t* out) {
@@ -981,6 +1013,24 @@ void launchTraceRays(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg,
   Geo g = traversalGeo(lc, sc, count);
   if (sc.ldsBytes) { allowLds(lc, (const void*)k_trace_rays<true>, g.lds); hipLaunchKernelGGL(k_trace_rays<true>, g.grid, g.block, g.lds, lc.stream, sc, cfg.eps, rays6, count, triId, t, u, v, normal3); }
   else hipLaunchKernelGGL(k_trace_rays<false>, g.grid, g.block, 0, lc.stream, sc, cfg.eps, rays6, count, triId, t, u, v, normal3);
+}
+
+template <bool BOTH>
+static void launchTraceTexT(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const float* tex6, const float* rays6,
+                            uint32_t count, int32_t* result, int32_t* triId, float* t, float* tc2) {
+  Geo g = traversalGeo(lc, sc, count);
+  if (sc.ldsBytes) {
+    allowLds(lc, (const void*)k_trace_tex<true, BOTH>, g.lds);
+    hipLaunchKernelGGL((k_trace_tex<true, BOTH>), g.grid, g.block, g.lds, lc.stream, sc, cfg.eps, tex6, rays6, count, result, triId, t, tc2);
+  } else {
+    hipLaunchKernelGGL((k_trace_tex<false, BOTH>), g.grid, g.block, 0, lc.stream, sc, cfg.eps, tex6, rays6, count, result, triId, t, tc2);
+  }
+}
+
+void launchTraceTex(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const float* tex6, const float* rays6,
+                    uint32_t count, bool ignoreBackfaces, int32_t* result, int32_t* triId, float* t, float* tc2) {
+  if (ignoreBackfaces) launchTraceTexT<false>(lc, sc, cfg, tex6, rays6, count, result, triId, t, tc2);
+  else launchTraceTexT<true>(lc, sc, cfg, tex6, rays6, count, result, triId, t, tc2);
 }
 
 void launchHitsNothing(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const float* rays6, uint32_t count, uint8_t* out) {

@@ -102,6 +102,26 @@ PT_HD V3 interpNormal(V3 n0, V3 n1, V3 n2, float u, float v) {
   return normalized(n0 * i2 + interpolated1 * i1);
 }
 
+// interpolate(u, v, val0, val1, val2) of the texcoord variant of Scene.trace, one component (scene.d:68-105):
+// the weights of interpNormal with u, v clamped at 0 and the u + v == 0 corner defined
+PT_HD float interpolateComponent(float u, float v, float val0, float val1, float val2) {
+  if (u < 0.0f) u = 0.0f;
+  if (v < 0.0f) v = 0.0f;
+  float uv = (u + v);
+  float u1, v1;
+  if (uv != 0.0f) { float x = 1.0f / uv; u1 = x * u; v1 = x * v; }
+  else { u1 = u; v1 = v; }
+  const float sqrt2 = 1.414213562f;
+  float d1 = sqrtf((1.0f - u1) * (1.0f - u1) + v1 * v1) / sqrt2;
+  float d2 = sqrtf(u1 * u1 + (1.0f - v1) * (1.0f - v1)) / sqrt2;
+  float interpolated1 = val1 * d1 + val2 * d2;
+  float i1;
+  if (uv != 0.0f) { float len = sqrtf(u1 * u1 + v1 * v1); i1 = sqrtf(u * u + v * v) / len; }
+  else i1 = 0.0f;
+  float i2 = 1.0f - i1;
+  return val0 * i2 + interpolated1 * i1;
+}
+
 // rendering.d:309-314
 PT_HD V3 angleToLocalDirection(float phi, float psi) {
   float cosPhi = cosf(phi);

@@ -114,6 +114,18 @@ void flattenModel(const ModelData& model, int materialTable, const float* modelM
         }
         out.matIdx.push_back(mesh.materialIndex);
       }
+      // TriangleData.tex, scene.d:305-307.  The reference indexes texcoord set 1; a mesh that has fewer sets
+      // (every model shipped with it) would fail its bounds check there, so the last set present is taken
+      // instead, and (0, 0) when the mesh has none.
+      const std::vector<float>* tc = nullptr;
+      if (mesh.texcoords[1].size() == nv * 2) tc = &mesh.texcoords[1];
+      else for (int s = 3; s >= 0 && !tc; s--) if (mesh.texcoords[s].size() == nv * 2 && nv) tc = &mesh.texcoords[s];
+      for (size_t f = 0; f < nf; f++)
+        for (int k = 0; k < 3; k++) {
+          uint32_t idx = mesh.faces[3 * f + k];
+          out.tex.push_back(tc ? (*tc)[2 * idx] : 0.0f);
+          out.tex.push_back(tc ? (*tc)[2 * idx + 1] : 0.0f);
+        }
     }
   }
 }

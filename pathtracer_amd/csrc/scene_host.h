@@ -12,6 +12,7 @@ namespace pt {
 struct FlatScene {                       // Scene.m_triangles / m_data / m_materials as plain arrays
   std::vector<float> v;                  // T x 9  (v0, v1, v2)
   std::vector<float> n;                  // T x 9  vertex normals
+  std::vector<float> tex;                // T x 6  TriangleData.tex (scene.d:305-307); empty = all zero
   std::vector<uint32_t> matIdx;          // T
   std::vector<PtMaterial> mats;          // M
   std::vector<std::string> matNames;     // M

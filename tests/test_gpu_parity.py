@@ -104,6 +104,36 @@ def test_scene_trace_and_hits_nothing_on_random_rays(require_gpu, name, flats):
     assert 0 < free.sum() < len(rays)
 
 
+@pytest.mark.parametrize('name', NAMES)
+@pytest.mark.parametrize('lds', [True, False])
+def test_texcoord_trace_equals_oracle(require_gpu, name, lds, flats):
+    """Scene.trace's texcoord variant (scene.d:745-796) for both IgnoreBackfaces values: TraceResult and triangle
+    ids bit-exact, rayPos and the interpolated texcoords bit-equal (same fixed fp32 sequence on both sides)."""
+    pt = make_tracer(name, 16, 16, flags=0 if lds else P.PT_FLAG_NO_LDS_SCENE)
+    assert pt.stats().sceneInLds == (1 if lds else 0)
+    o = make_oracle(flats[name], name, 16, 16)
+    rays = random_rays(flats[name], 30000, 7)
+    for ignore in (True, False):
+        res, tri, t, tc = pt.trace_tex(rays, ignore_backfaces=ignore)
+        ores, otri, ot, otc = o.trace_tex(rays, ignore_backfaces=ignore)
+        assert np.array_equal(res, ores) and np.array_equal(tri, otri)
+        hit = ores != 2
+        assert np.all(np.abs(t[hit] - ot[hit]) <= TOL * np.abs(ot[hit])) and np.all(np.abs(tc - otc) <= TOL)
+        assert np.array_equal(t.view(np.uint32), ot.view(np.uint32))
+        assert np.array_equal(tc.view(np.uint32), otc.view(np.uint32))
+        assert (res == 0).sum() > 500 and ((res == 1).sum() > 500) == (not ignore)
+        assert np.abs(tc[hit]).max() > 0
+    # caller-supplied texcoords replace the file's
+    tex = np.random.default_rng(1).random(flats[name]['tex'].shape).astype(np.float32)
+    pt.set_texcoords(tex)
+    fl2 = dict(flats[name]); fl2['tex'] = tex
+    o2 = oracle_py.Oracle(fl2, build_tree=False)
+    res, tri, t, tc = pt.trace_tex(rays[:5000], ignore_backfaces=False)
+    ores, otri, ot, otc = o2.trace_tex(rays[:5000], ignore_backfaces=False)
+    assert np.array_equal(res, ores) and np.array_equal(tc.view(np.uint32), otc.view(np.uint32))
+    assert len(pt.trace_tex(np.zeros((0, 6), np.float32))[0]) == 0
+
+
 def test_scene_traversed_from_global_memory_gives_the_same_hits(require_gpu, flats):
     """PT_FLAG_NO_LDS_SCENE: the HBM/L2 variant of every traversal kernel against the LDS-staged one."""
     name, W, H = 'teapot', 320, 180

@@ -251,3 +251,99 @@ def test_constant_sky_mask_never_hides_the_sun_disc_or_geometry():
     pt.set_camera(oracle_py.camera_lookat(30.0, H / W, (20, 20, 120), (0, 0, 0), UP))
     covered, const_sky = pt.coverage_mask(constant_sky=True)
     assert np.array_equal(const_sky, ~covered)
+
+
+# ------------------------------------------------------------------ texcoord variant of Scene.trace (scene.d:745-796)
+def interpolate_np(u, v, val0, val1, val2):
+    """scene.d:68-105 in numpy float32, one operator per rounding."""
+    f = np.float32
+    u = np.maximum(f(u), f(0)); v = np.maximum(f(v), f(0))
+    uv = f(u + v)
+    if uv != 0:
+        x = f(f(1) / uv); u1 = f(x * u); v1 = f(x * v)
+    else:
+        u1, v1 = u, v
+    sqrt2 = f(1.414213562)
+    d1 = f(np.sqrt(f(f(f(1) - u1) * f(f(1) - u1)) + f(v1 * v1)) / sqrt2)
+    d2 = f(np.sqrt(f(f(u1 * u1) + f(f(f(1) - v1) * f(f(1) - v1)))) / sqrt2)
+    ip = f(f(val1 * d1) + f(val2 * d2))
+    if uv != 0:
+        ln = f(np.sqrt(f(f(u1 * u1) + f(v1 * v1))))
+        i1 = f(f(np.sqrt(f(f(u * u) + f(v * v)))) / ln)
+    else:
+        i1 = f(0)
+    i2 = f(f(1) - i1)
+    return f(f(val0 * i2) + f(ip * i1))
+
+
+def one_triangle_scene():
+    """One triangle in the z = 0 plane, counter-clockwise seen from +z, with distinct texcoords per vertex."""
+    v = np.array([[[0, 0, 0], [4, 0, 0], [0, 4, 0]]], np.float32)
+    n = np.tile(np.array([0, 0, 1], np.float32), (1, 3, 1))
+    fl = {'v': v, 'n': n, 'mat_idx': np.zeros(1, np.uint32), 'materials': np.array([[0, .5, .5, .5]], np.float32),
+          'tex': np.array([[[0.25, 0.5], [1.0, 0.0], [0.0, 2.0]]], np.float32)}
+    return fl
+
+
+def test_oracle_texcoord_trace_known_answers():
+    """Corners return the vertex values (u weights vertex 2, v vertex 1), back faces are reported or ignored,
+    and interior points follow the numpy restatement of interpolate()."""
+    fl = one_triangle_scene()
+    o = oracle_py.Oracle(fl, build_tree=False)
+    down = lambda x, y: [x, y, 5, 0, 0, -1]
+    up = lambda x, y: [x, y, -5, 0, 0, 1]
+    rays = np.array([down(0, 0), down(4, 0), down(0, 4), down(1, 1), down(0.5, 2.5), down(9, 9), up(1, 1)], np.float32)
+    res, tri, t, tc = o.trace_tex(rays, ignore_backfaces=False)
+    sides = res[[0, 3, 6]]
+    assert set(sides[:2]) == {sides[0]} and sides[2] == 1 - sides[0]      # one side front, the other back
+    assert res[5] == 2 and tri[5] == -1 and t[5] > 3e38 and np.array_equal(tc[5], [0, 0])
+    assert np.array_equal(tri[[0, 1, 2, 3, 4, 6]], np.zeros(6, np.int32)) and np.allclose(t[[0, 1, 2, 3, 4, 6]], 5)
+    tex = fl['tex'][0]
+    assert np.allclose(tc[0], tex[0], atol=1e-6)
+    # which corner u and v weight is fixed by the intersection routine; both orders of (4,0) and (0,4) are vertex values
+    assert {tuple(np.round(tc[1], 5)), tuple(np.round(tc[2], 5))} == {tuple(tex[1]), tuple(tex[2])}
+    res_f, tri_f, t_f, tc_f = o.trace_tex(rays, ignore_backfaces=True)
+    back = res == 1
+    assert (res_f[back] == 2).all() and (tri_f[back] == -1).all() and np.array_equal(res_f[~back], res[~back])
+    # interior: recompute from the oracle's own (u, v) of the plain trace
+    front_rays = rays[res == 0]
+    otri, ot, ou, ov = o.trace_rays(front_rays, kind=0, use_tree=False)
+    for i in range(len(front_rays)):
+        for c in range(2):
+            e = interpolate_np(ou[i], ov[i], tex[0][c], tex[1][c], tex[2][c])
+            assert tc[res == 0][i][c] == e
+
+
+def test_texcoord_trace_agrees_with_plain_trace_on_front_faces(flats):
+    """With back faces ignored the variant finds exactly the hits of Scene.trace (scene.d:681-743)."""
+    from test_gpu_parity import random_rays
+    fl = flats['teapot']
+    o = oracle_py.Oracle(fl, build_tree=False)
+    rays = random_rays(fl, 3000, 9)
+    res, tri, t, tc = o.trace_tex(rays, ignore_backfaces=True)
+    otri, ot, ou, ov = o.trace_rays(rays, kind=0, use_tree=False)
+    assert np.array_equal(tri, otri) and np.array_equal(t.view(np.uint32), ot.view(np.uint32))
+    assert np.array_equal(res == 0, otri >= 0) and not (res == 1).any()
+    res2, tri2, t2, _ = o.trace_tex(rays, ignore_backfaces=False)
+    assert (res2 == 1).sum() > 100 and (t2 <= t).all()
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_flattened_texcoords_equal_reader_restatement(name, flats):
+    """TriangleData.tex (scene.d:305-307) as the product's reader flattens it vs the Python restatement of the reader."""
+    got = host_tracer(name).get_texcoords()
+    assert np.array_equal(got.view(np.uint32), flats[name]['tex'].astype(np.float32).view(np.uint32))
+    assert np.abs(got).max() > 0
+
+
+def test_texcoords_of_uploaded_scenes_default_to_zero_and_can_be_set():
+    fl = soup(50, seed=3)
+    pt = host_tracer(flat=fl)
+    assert not pt.get_texcoords().any()
+    tex = np.random.default_rng(0).random((len(fl['v']), 3, 2)).astype(np.float32)
+    pt.set_texcoords(tex)
+    assert np.array_equal(pt.get_texcoords(), tex)
+    with pytest.raises(ValueError):
+        pt.set_texcoords(tex[:10])
+    pt.upload_scene(fl['v'], fl['n'], fl['mat_idx'], fl['materials'])      # a new scene drops them
+    assert not pt.get_texcoords().any()
