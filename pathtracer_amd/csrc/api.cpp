@@ -59,7 +59,7 @@ struct PtHandle {
   DevScene dsc{};
   DevBuf accOwn; float4* acc = nullptr; uint64_t accBytes = 0;
   // wavefront buffers
-  DevBuf bSlotQ, bHitA, bHitB, bRayO, bRayD, bLacc, bThr, bRng, bShO, bShD, bShW, bCounters, bStats;
+  DevBuf bSlotQ, bHitA, bHitB, bRayO, bRayD, bLacc, bThr, bRng, bShO, bShD, bShW, bShX, bCounters, bStats;
   SceneBox box{};
   // coverage mask of the view rays (scene_host.h: buildCoverageMask); rebuilt when the scene or the camera changes
   DevBuf dMask, dSkyMask; bool maskDirty = true, maskUsable = false;
@@ -154,8 +154,8 @@ void uploadScene(PtHandle* h) {
   for (uint32_t i = 0; i < T; i++)
     if (fs.matIdx[i] >= fs.mats.size()) fail(PT_E_INVALID, "material index out of range at triangle " + std::to_string(i));
   findLights(fs, h->lights);
-  if (h->lights.numGroups() + 2 > (size_t)PT_MAX_KINDS)
-    fail(PT_E_INVALID, "more than " + std::to_string(PT_MAX_KINDS - 2) + " emissive materials");
+  if (h->lights.numGroups() + 1 > (size_t)PT_MAX_KINDS)
+    fail(PT_E_INVALID, "more than " + std::to_string(PT_MAX_KINDS - 1) + " emissive materials");
   // The binned-SAH build on one host core takes ~1 s per million triangles; from 1 M triangles up the tree is built
   // on the GPU instead (Morton-order LBVH: more traversal steps per ray, but the soup builds in a fraction of a second).
   const uint32_t f = h->cfg.flags;
@@ -234,7 +234,7 @@ void uploadScene(PtHandle* h) {
   h->st.numLightGroups = d.numLightGroups; h->st.sceneInLds = d.ldsBytes ? 1 : 0;
 }
 
-uint32_t numKinds(const PtHandle* h) { return h->dsc.numLightGroups + 2; }
+uint32_t numKinds(const PtHandle* h) { return h->dsc.numLightGroups + 1; }
 
 void ensureWavefront(PtHandle* h) {
   const PtConfig& c = h->cfg;
@@ -255,7 +255,7 @@ void ensureWavefront(PtHandle* h) {
     if (h->wf.capSlots && h->wf.lanes == lanes && h->wfKinds == numKinds(h) && h->wfRounds == (c.mode == 1 ? c.maxDepth + 4 : 2)) return;
     size_t freeB = 0, totalB = 0;
     HIPCHECK(hipMemGetInfo(&freeB, &totalB));
-    uint64_t perSlot = 16 + 16ull * lanes + (NI ? 24ull * lanes : 0) + (uint64_t)std::max(1u, NI) * (32 + (NI ? 32 : 0) + 48ull * numKinds(h));
+    uint64_t perSlot = 16 + 16ull * lanes + (NI ? 24ull * lanes : 0) + (uint64_t)std::max(1u, NI) * (32 + (NI ? 32 : 0) + 48ull * numKinds(h) + 16);
     uint64_t held = h->wf.capSlots ? (uint64_t)h->wf.capSlots * perSlot : 0;       // what this handle would give back
     while (want > gran && want * perSlot > (freeB + held) / 2) want /= 2;
   }
@@ -276,6 +276,7 @@ void ensureWavefront(PtHandle* h) {
   h->bShO.alloc((uint64_t)kinds * capQueue * 16);
   h->bShD.alloc((uint64_t)kinds * capQueue * 16);
   h->bShW.alloc((uint64_t)kinds * capQueue * 16);
+  h->bShX.alloc(capQueue * 16);
   // queue bookkeeping: stage s owns 2 + PT_MAX_KINDS queues: [0] the hit queue its extend fills, [1] the ray queue
   // and [2 + kind] the shadow queues its shade fills
   const uint32_t perStage = 2 + PT_MAX_KINDS;
@@ -293,21 +294,21 @@ void ensureWavefront(PtHandle* h) {
   w.slotQ = h->bSlotQ.as<float4>(); w.hitA = h->bHitA.as<float4>(); w.hitB = h->bHitB.as<float4>();
   w.rayO = h->bRayO.as<float4>(); w.rayD = h->bRayD.as<float4>();
   w.Lacc = h->bLacc.as<float4>(); w.thr = h->bThr.as<float4>(); w.rng = h->bRng.as<uint2>();
-  w.shO = h->bShO.as<float4>(); w.shD = h->bShD.as<float4>(); w.shW = h->bShW.as<float4>();
+  w.shO = h->bShO.as<float4>(); w.shD = h->bShD.as<float4>(); w.shW = h->bShW.as<float4>(); w.shX = h->bShX.as<float4>();
   w.stats = h->bStats.as<unsigned long long>();
   w.capSlots = capSlots; w.capQueue = (uint32_t)capQueue; w.capHit = (uint32_t)capHit; w.lanes = lanes;
   h->wfKinds = kinds; h->wfRounds = rounds;
 }
 
-// Shadow rays of one vertex generation: light groups by Scene.trace, sun and sky by Scene.hitsNothing.
-void launchShadowKinds(PtHandle* h, const LaunchCfg& lc, const DevCfg& dc, const Wavefront& wf) {
+// Shadow rays of one vertex generation: light groups by Scene.trace, sun and sky (one queue) by Scene.hitsNothing.
+void launchShadowKinds(PtHandle* h, const LaunchCfg& lc, const DevCfg& dc, const Wavefront& wf, bool primary) {
   int kind = 0;
   if (dc.hasLights)
     for (uint32_t li = 0; li < h->dsc.numLightGroups; li++, kind++) {
       Timed t(h, PT_K_CONNECT); launchConnect(lc, h->dsc, dc, wf, kind, h->lights.totalArea[li]); t.done();
     }
   if (dc.hasSky)
-    for (int s = 0; s < 2; s++, kind++) { Timed t(h, PT_K_OCCLUDED); launchOccluded(lc, h->dsc, dc, wf, kind); t.done(); }
+    { Timed t(h, PT_K_OCCLUDED); launchOccluded(lc, h->dsc, dc, wf, kind, primary); t.done(); }
 }
 
 // One wavefront batch: npix pixels x k samples.  Counter set s belongs to stage s: 0 = raygen, 1 = shading of the
@@ -315,7 +316,7 @@ void launchShadowKinds(PtHandle* h, const LaunchCfg& lc, const DevCfg& dc, const
 void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm) {
   Wavefront wf = h->wf;
   const uint32_t perStage = 2 + PT_MAX_KINDS;
-  const int kinds = (int)((dc.hasLights ? h->dsc.numLightGroups : 0) + (dc.hasSky ? 2 : 0));
+  const int kinds = (int)((dc.hasLights ? h->dsc.numLightGroups : 0) + (dc.hasSky ? 1 : 0));
   const QMeta* desc = h->bMetaDesc.as<QMeta>();
   // stage s: 0 = raygen, 1 = view-ray hits, 2 + r = indirect hits of round r.  Per stage: extend reads the previous
   // stage's ray queue and fills the hit queue [0]; shade reads it and fills the ray queue [1] and shadow queues
@@ -335,7 +336,7 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm) 
     scan((size_t)s * perStage, 1);
     { Timed t(h, PT_K_SHADE); launchShade(lc, h->dsc, dc, pm, h->acc, wf, primary); t.done(); }
     scan((size_t)s * perStage + 1, 1 + kinds);
-    launchShadowKinds(h, lc, dc, wf);
+    launchShadowKinds(h, lc, dc, wf, primary);
   };
   uint32_t nslots = pm.npix * pm.k;
   wf.rayOut = h->metas[1];

@@ -86,7 +86,7 @@ PT_HD uint32_t mapPixel(const PixMap& pm, uint32_t W, uint32_t lp) {
   return (pm.bandFirst + j * pm.bandStride) * pm.bandPix + r;
 }
 
-constexpr int PT_MAX_KINDS = 10;    // shadow-ray kinds per vertex: light groups + sun + sky
+constexpr int PT_MAX_KINDS = 10;    // shadow queues per vertex: one per light group + one for the sun and sky rays
 
 // Queues are SEGMENTED: every stage splits its input into PT_SEGS block-tasks of P consecutive entries, and
 // block-task T appends what it emits to segment T of each output queue (entries T*segCap .. T*segCap+count[T]).
@@ -127,6 +127,8 @@ struct Wavefront {
   float4* shO;                // shadow queues, kind-major: (origin.xyz, lane slot)
   float4* shD;                //                            (dir.xyz, light distance)
   float4* shW;                //                            (weight.xyz, n.omega)
+  float4* shX;                // the sun/sky queue (the last kind) holds (origin, lane slot), (sun dir, n.sunDir),
+                              // (sky dir, n.dir) in shO/shD/shW and a fourth vector here: see k_occluded
   QMeta rayIn;                // slot / ray queue this stage's extend reads (filled by the previous stage)
   QMeta hitQ;                 // hit queue of this stage: extend fills it, shade reads it
   QMeta rayOut;               // ray queue this stage's shade fills
@@ -142,6 +144,12 @@ struct Wavefront {
 enum { STAT_RAYS_LIGHT = 0, STAT_RAYS_INDIRECT, STAT_RAYS_OCCL, STAT_NODES_CLOSEST, STAT_TRIS_CLOSEST,
        STAT_NODES_ANY, STAT_TRIS_ANY, STAT_RAYS_CULLED, STAT_COUNT };
 
+// Whether the sun/sky kernel stores L of a vertex outright instead of adding to it: view-ray hits of a scene in which
+// no light-group kernel adds to L before it.
+PT_HD bool envDirect(const DevCfg& cfg, const DevScene& sc, bool primary) {
+  return primary && cfg.hasSky && !(cfg.hasLights && sc.numLightGroups);
+}
+
 struct LaunchCfg { int device; int numCUs; bool countVisits; hipStream_t stream; };
 
 // ---- wavefront stages (all asynchronous on lc.stream) ----
@@ -156,7 +164,8 @@ void launchExtend(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, co
 void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
                  const Wavefront& wf, bool primary);
 void launchConnect(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, float area);
-void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind);
+// primary: the queue was filled by the shading of view-ray hits
+void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, bool primary);
 void launchAccumulate(const LaunchCfg& lc, const ViewMasks& masks, const DevCfg& cfg, const PixMap& pm, float4* acc,
                       const Wavefront& wf);
 

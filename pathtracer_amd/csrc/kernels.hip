@@ -112,6 +112,9 @@ struct Hit { float t, u, v; uint32_t tri; bool front; };
 #ifndef PT_RAYGEN_THREADS
 #define PT_RAYGEN_THREADS 256
 #endif
+#ifndef PT_RAYGEN_UNROLL
+#define PT_RAYGEN_UNROLL 4
+#endif
 #ifndef PT_SHADE_THREADS
 #define PT_SHADE_THREADS 256
 #endif
@@ -404,14 +407,14 @@ __device__ __forceinline__ uint32_t slotPixel(const DevCfg& cfg, const PixMap& p
 }
 __device__ __forceinline__ bool maskBit(const uint32_t* __restrict__ m, uint32_t p) { return (m[p >> 5] >> (p & 31u)) & 1u; }
 
-__device__ __forceinline__ PrimaryRay primaryRayAt(const DevCfg& cfg, const float4* __restrict__ acc, uint32_t gp, uint32_t s,
-                                                   bool jitter) {
+// accW: the pixel's sample count so far (Pixel.n), which numbers the sample
+__device__ __forceinline__ PrimaryRay primaryRayFrom(const DevCfg& cfg, uint32_t gp, uint32_t s, float accW, bool jitter) {
   PrimaryRay r;
   r.gp = gp;
   uint32_t row = fdiv(cfg.divW, r.gp), col = r.gp - row * cfg.W;
   float x, y;
   if (jitter) {
-    r.sampleIdx = cfg.sampleBase + (uint32_t)acc[r.gp].w + s;
+    r.sampleIdx = cfg.sampleBase + (uint32_t)accW + s;
     r.g.seed(cfg.seed, r.gp, r.sampleIdx, 0);
     viewRayXY(col, row, cfg.W, cfg.H, &r.g, x, y);
   } else {
@@ -420,6 +423,10 @@ __device__ __forceinline__ PrimaryRay primaryRayAt(const DevCfg& cfg, const floa
   }
   r.d = screenRayDir(cfg.cam, x, y);
   return r;
+}
+__device__ __forceinline__ PrimaryRay primaryRayAt(const DevCfg& cfg, const float4* __restrict__ acc, uint32_t gp, uint32_t s,
+                                                   bool jitter) {
+  return primaryRayFrom(cfg, gp, s, jitter ? acc[gp].w : 0.0f, jitter);
 }
 __device__ __forceinline__ PrimaryRay primaryRay(const DevCfg& cfg, const PixMap& pm, const float4* __restrict__ acc, uint32_t i,
                                                  bool jitter) {
@@ -443,26 +450,47 @@ __global__ void __launch_bounds__(PT_RAYGEN_THREADS) k_raygen(SceneBox box, View
   __syncthreads();
   uint32_t T = blockIdx.x, P = dense64(nslots), begin = T * P, end = min(begin + P, nslots);
   uint32_t segCap = wf.capSlots / PT_SEGS, culled = 0;
-  for (uint32_t base = begin; base < end; base += blockDim.x) {
-    uint32_t i = base + threadIdx.x;
-    bool enter = false;
-    V3 d = v3(0, 0, 0);
-    if (i < end) {
-      uint32_t s, gp = slotPixel(cfg, pm, i, s);
-      if (masks.constantSky && maskBit(masks.constantSky, gp)) culled++;
-      else {
-        d = primaryRayAt(cfg, acc, gp, s, true).d;
-        if (masks.covered) enter = maskBit(masks.covered, gp);
-        else {
-          RayInv ri = makeRayInv(cfg.cam.pos, d);
+  // PT_RAYGEN_UNROLL slots per lane and pass, phase by phase: the loads of a phase (mask words, then sample counts)
+  // are in flight together, so a pass waits through two memory round trips for four slots, not per slot
+  constexpr int U = PT_RAYGEN_UNROLL;
+  for (uint32_t base = begin; base < end; base += blockDim.x * U) {
+    uint32_t i[U], s[U], gp[U];
+    bool valid[U], constant[U], enter[U];
+    float accW[U];
+    V3 d[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      i[u] = base + u * blockDim.x + threadIdx.x;
+      valid[u] = i[u] < end;
+      gp[u] = slotPixel(cfg, pm, valid[u] ? i[u] : begin, s[u]);
+      constant[u] = valid[u] && masks.constantSky && maskBit(masks.constantSky, gp[u]);
+      enter[u] = false;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      bool live = valid[u] && !constant[u];
+      accW[u] = live ? acc[gp[u]].w : 0.0f;
+      if (live && masks.covered) enter[u] = maskBit(masks.covered, gp[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      d[u] = v3(0, 0, 0);
+      if (constant[u]) culled++;
+      else if (valid[u]) {
+        d[u] = primaryRayFrom(cfg, gp[u], s[u], accW[u], true).d;
+        if (!masks.covered) {
+          RayInv ri = makeRayInv(cfg.cam.pos, d[u]);
           float tn;
-          enter = slab(ri, box.mn[0], box.mn[1], box.mn[2], box.mx[0], box.mx[1], box.mx[2], PT_FLT_MAX, tn);
+          enter[u] = slab(ri, box.mn[0], box.mn[1], box.mn[2], box.mx[0], box.mx[1], box.mx[2], PT_FLT_MAX, tn);
         }
-        if (!enter) { wf.Lacc[i] = f4(sampleSky(d), 0.0f); culled++; }        // rendering.d:480
+        if (!enter[u]) { wf.Lacc[i[u]] = f4(sampleSky(d[u]), 0.0f); culled++; }        // rendering.d:480
       }
     }
-    uint32_t idx = waveAppend(enter, &sCnt);
-    if (enter) wf.slotQ[T * segCap + idx] = f4(d, u2f(i));
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      uint32_t idx = waveAppend(enter[u], &sCnt);
+      if (enter[u]) wf.slotQ[T * segCap + idx] = f4(d[u], u2f(i[u]));
+    }
   }
   for (int off = 32; off > 0; off >>= 1) culled += __shfl_down(culled, off);
   if ((threadIdx.x & 63) == 0 && culled) atomicAdd(&wf.stats[STAT_RAYS_CULLED], (unsigned long long)culled);
@@ -587,34 +615,51 @@ __global__ void PT_TRAVERSAL_BOUNDS k_connect(DevScene sc, float eps, QMeta q, u
   flushCounts<COUNT>(stats, STAT_NODES_CLOSEST, cN, cT);
 }
 
-// Sun / sky rays: Scene.hitsNothing + `L += ...`, rendering.d:440-443 and 455-457.
+// Sun and sky rays of one vertex: Scene.hitsNothing + `L += ...`, rendering.d:440-443 and 455-457.  An entry is
+// (origin, lane slot), (sun direction, n.sunDir), (sky direction, n.dir) and X; a zero direction is not traced.
+// direct: the vertex is a view-ray hit whose L nothing else adds to before this kernel; X = (color, emissive) and the
+// kernel stores L = emissive * color + ... (rendering.d:477) without reading it.  Otherwise X = (BRDF * color scaled
+// by the chain's throughput, -) and L is read, added to and written back when a ray got through.
 template <bool LDSS, bool COUNT>
-__global__ void PT_TRAVERSAL_BOUNDS k_occluded(DevScene sc, float eps, QMeta q, uint32_t segCap, const float4* __restrict__ shO,
-                                                   const float4* __restrict__ shD, const float4* __restrict__ shW,
+__global__ void PT_TRAVERSAL_BOUNDS k_occluded(DevScene sc, float eps, V3 sunRadiance, V3 skyRadiance, int direct, QMeta q,
+                                                   uint32_t segCap, const float4* __restrict__ shO, const float4* __restrict__ shD,
+                                                   const float4* __restrict__ shW, const float4* __restrict__ shX,
                                                    uint32_t* taskCounter, float4* __restrict__ Lacc, unsigned long long* stats) {
   __shared__ __align__(16) WorkPool pool;
   initPool(&pool);
   stageScene<LDSS>(sc);
   __syncthreads();
-  uint32_t cN = 0, cT = 0;
+  uint32_t cN = 0, cT = 0, nRays = 0;
   const uint32_t total = q.prefix[PT_SEGS];
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[STAT_RAYS_OCCL], (unsigned long long)total);
   Chunk ck;
   while (nextChunk(&pool, taskCounter, q, total, 0, ck)) {
     uint32_t j = ck.begin + (threadIdx.x & 63u);
     if (j < ck.end) {
       uint32_t e = physIndexHint(q, j, ck.seg, segCap);
-      float4 ro = shO[e], rd = shD[e];
+      float4 ro = shO[e], a = shD[e], b = shW[e];
+      bool eSun = a.x != 0.0f || a.y != 0.0f || a.z != 0.0f, eSky = b.x != 0.0f || b.y != 0.0f || b.z != 0.0f;
+      nRays += (eSun ? 1u : 0u) + (eSky ? 1u : 0u);
+      // One traversal after the other, each with the lanes that have that ray.  (Both rays of a lane in one loop, the
+      // sky ray starting as soon as the lane's sun ray is decided, was measured 5 % slower: sun rays are nearly
+      // parallel and walk the tree together, and mixing them with sky rays breaks that up.)
+      bool vSun = false, vSky = false;
       Hit h;
-      if (!traverse<true, LDSS, COUNT>(sc, xyz(ro), xyz(rd), eps, h, cN, cT)) {
-        float4 w = shW[e];
+      if (eSun) vSun = !traverse<true, LDSS, COUNT>(sc, xyz(ro), xyz(a), eps, h, cN, cT);
+      if (eSky) vSky = !traverse<true, LDSS, COUNT>(sc, xyz(ro), xyz(b), eps, h, cN, cT);
+      if (direct || vSun || vSky) {
+        float4 x = shX[e];
         uint32_t slot = f2u(ro.w);
-        float4 L = Lacc[slot];
-        L.x = L.x + w.x; L.y = L.y + w.y; L.z = L.z + w.z;
+        V3 Tw; float4 L;
+        if (direct) { V3 color = xyz(x); Tw = v3(1, 1, 1) * (PT_BRDF * color); L = f4(x.w * color, 1.0f); }
+        else { Tw = xyz(x); L = Lacc[slot]; }
+        if (vSun) { V3 c = Tw * sunRadiance * a.w; L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; }
+        if (vSky) { V3 c = Tw * skyRadiance * b.w; L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; }
         Lacc[slot] = L;
       }
     }
   }
+  for (int off = 32; off > 0; off >>= 1) nRays += __shfl_down(nRays, off);
+  if ((threadIdx.x & 63) == 0 && nRays) atomicAdd(&stats[STAT_RAYS_OCCL], (unsigned long long)nRays);
   flushCounts<COUNT>(stats, STAT_NODES_ANY, cN, cT);
 }
 
@@ -657,8 +702,10 @@ __device__ __forceinline__ void emitShadow(ShadeCtx& cx, int kind, bool emit, V3
   }
 }
 
-// computeLdirect up to (not including) the trace calls, rendering.d:396-462: emits one shadow ray per kind.
-__device__ __forceinline__ void directLight(ShadeCtx& cx, bool active, Rng& g, V3 x, V3 normalX, V3 Tw, uint32_t laneSlot) {
+// computeLdirect up to (not including) the trace calls, rendering.d:396-462: emits one shadow ray per light group and
+// one entry for the sun and sky rays together (envX: what the kernel that traces them needs besides, see k_occluded).
+// Returns whether the lane emitted that entry.
+__device__ __forceinline__ bool directLight(ShadeCtx& cx, bool active, Rng& g, V3 x, V3 normalX, V3 Tw, float4 envX, uint32_t laneSlot) {
   const DevScene& sc = cx.sc; const DevCfg& cfg = cx.cfg;
   float eps = cfg.eps;
   int kind = 0;
@@ -687,33 +734,36 @@ __device__ __forceinline__ void directLight(ShadeCtx& cx, bool active, Rng& g, V
       emitShadow(cx, kind, emit, x + normalX * eps, phi, lightDistance, Tw, ndot, laneSlot);
     }
   }
+  bool emitted = false;
   if (cfg.hasSky) {
-    {  // sun, rendering.d:432-445
-      bool emit = false; V3 dir = v3(0, 0, 0), c = v3(0, 0, 0);
-      if (active) {
-        float psi = g.uniform(0.0f, 2.0f * PT_PI_F);
-        float phi = g.uniform(PT_PI_2_F - PT_PI_2_F * 0.01f, PT_PI_2_F);
-        dir = angleToDirection(phi, psi, cfg.sunDir);
-        emit = dot(normalX, dir) > eps;
-        c = Tw * cfg.sunRadiance * dot(normalX, cfg.sunDir);
-      }
-      emitShadow(cx, kind, emit, x + normalX * 0.1f, dir, 0.0f, c, 0.0f, laneSlot);
-      kind++;
+    // sun (rendering.d:432-445) and sky (rendering.d:448-459) leave from the same point: one entry carries both
+    // directions, each with the cosine its radiance is weighted with; a direction that is not traced is stored as 0
+    bool eSun = false, eSky = false; V3 dSun = v3(0, 0, 0), dSky = v3(0, 0, 0); float sSun = 0.0f, sSky = 0.0f;
+    if (active) {
+      float psi = g.uniform(0.0f, 2.0f * PT_PI_F);
+      float phi = g.uniform(PT_PI_2_F - PT_PI_2_F * 0.01f, PT_PI_2_F);
+      dSun = angleToDirection(phi, psi, cfg.sunDir);
+      eSun = dot(normalX, dSun) > eps;
+      sSun = dot(normalX, cfg.sunDir);
+      psi = g.uniform(0.0f, 2.0f * PT_PI_F);
+      phi = g.uniform(0.0f, PT_PI_2_F);
+      dSky = angleToLocalDirection(phi, psi);
+      sSky = dot(normalX, dSky);
+      eSky = sSky > eps;
     }
-    {  // sky, rendering.d:448-459
-      bool emit = false; V3 dir = v3(0, 0, 0), c = v3(0, 0, 0);
-      if (active) {
-        float psi = g.uniform(0.0f, 2.0f * PT_PI_F);
-        float phi = g.uniform(0.0f, PT_PI_2_F);
-        dir = angleToLocalDirection(phi, psi);
-        float nd = dot(normalX, dir);
-        emit = nd > eps;
-        c = Tw * cfg.skyRadiance * nd;
-      }
-      emitShadow(cx, kind, emit, x + normalX * 0.1f, dir, 0.0f, c, 0.0f, laneSlot);
-      kind++;
+    emitted = eSun || eSky;
+    uint32_t idx = waveAppend(emitted, &cx.sCnt[1 + kind]);
+    if (emitted) {
+      size_t ex = cx.T * cx.segCapSh + idx, e = (size_t)kind * cx.wf.capQueue + ex;
+      if (!eSun) dSun = v3(0, 0, 0);
+      if (!eSky) dSky = v3(0, 0, 0);
+      cx.wf.shO[e] = f4(x + normalX * 0.1f, u2f(laneSlot));
+      cx.wf.shD[e] = f4(dSun, sSun);
+      cx.wf.shW[e] = f4(dSky, sSky);
+      cx.wf.shX[ex] = envX;
     }
   }
+  return emitted;
 }
 
 // PRIMARY: the part of computeL after the view-ray trace has hit (rendering.d:472-477); the generator of
@@ -730,6 +780,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg 
   uint32_t T = blockIdx.x;
   uint32_t segCap = wf.capQueue / PT_SEGS;
   ShadeCtx cx{sc, cfg, wf, sCnt, T, segCap, segCap};
+  const bool direct = envDirect(cfg, sc, PRIMARY);
   Task tk = taskOf(wf.hitQ, T);
   uint32_t seg = tk.seg;
   for (uint32_t base = tk.begin; base < tk.end; base += blockDim.x) {
@@ -737,6 +788,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg 
     bool active = j < tk.end;
     V3 Tp = v3(1, 1, 1), hitPos = v3(0, 0, 0), normal = v3(0, 0, 1), color = v3(0, 0, 0);
     uint32_t laneSlot = 0, depth = 0, gp = 0, sampleIdx = 0;
+    float emissive = 0.0f;
     Rng g; g.s0 = 1; g.s1 = 0;
     if (active) {
       uint32_t e = physIndex(wf.hitQ, j, seg, wf.capHit / PT_SEGS);
@@ -757,13 +809,12 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg 
       normal = interpNormal(xyz(q0), xyz(q1), xyz(q2), hb.x, hb.y);
       float4 m = sc.mats[f2u(q0.w)];
       color = v3(m.y, m.z, m.w);
-      if (PRIMARY) {
-        V3 em = m.x * color;                                           // emissive * color, rendering.d:477
-        wf.Lacc[laneSlot] = f4(em, 1.0f);
-      }
+      emissive = m.x;
     }
     V3 Tw = Tp * (PT_BRDF * color);
-    directLight(cx, active, g, hitPos, normal, Tw, laneSlot);
+    bool env = directLight(cx, active, g, hitPos, normal, Tw, direct ? f4(color, emissive) : f4(Tw, 0.0f), laneSlot);
+    // emissive * color, rendering.d:477; when the sun / sky entry carries it, the kernel that traces them stores L
+    if (PRIMARY && active && !(direct && env)) wf.Lacc[laneSlot] = f4(emissive * color, 1.0f);
     if (cfg.mode == 1) {
       if (PRIMARY) {
         for (uint32_t c = 0; c < cfg.numIndirect; c++) {               // the loop at rendering.d:474-476
@@ -985,16 +1036,17 @@ void launchConnect(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, c
                  (const float4*)(wf.shW + e), wf.taskCounters + 1 + kind, area, wf.Lacc, wf.stats);
 }
 
-void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind) {
+void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, bool primary) {
   Geo g = traversalGeo(lc, sc, wf.capQueue);
   size_t e = (size_t)kind * wf.capQueue;
-  PT_DISPATCH_LC(k_occluded, sc, cfg.eps, wf.sh[kind], wf.capQueue / PT_SEGS, (const float4*)(wf.shO + e), (const float4*)(wf.shD + e),
-                 (const float4*)(wf.shW + e), wf.taskCounters + 1 + kind, wf.Lacc, wf.stats);
+  PT_DISPATCH_LC(k_occluded, sc, cfg.eps, cfg.sunRadiance, cfg.skyRadiance, envDirect(cfg, sc, primary) ? 1 : 0, wf.sh[kind],
+                 wf.capQueue / PT_SEGS, (const float4*)(wf.shO + e), (const float4*)(wf.shD + e), (const float4*)(wf.shW + e),
+                 (const float4*)wf.shX, wf.taskCounters + 1 + kind, wf.Lacc, wf.stats);
 }
 
 void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
                  const Wavefront& wf, bool primary) {
-  int numKinds = (cfg.hasLights ? (int)sc.numLightGroups : 0) + (cfg.hasSky ? 2 : 0);
+  int numKinds = (cfg.hasLights ? (int)sc.numLightGroups : 0) + (cfg.hasSky ? 1 : 0);
   if (primary) hipLaunchKernelGGL(k_shade<true>, dim3(PT_SEGS), dim3(PT_SHADE_THREADS), 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
   else hipLaunchKernelGGL(k_shade<false>, dim3(PT_SEGS), dim3(PT_SHADE_THREADS), 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
 }
