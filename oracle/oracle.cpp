@@ -806,7 +806,8 @@ void orc_tonemap(const Pixel* pixels, uint32_t count, uint8_t* rgb) {
 // Traversal-cost model for the roofline: walks the PRODUCT's flattened BVH (nodes8 = {min.xyz, ref, max.xyz, 0},
 // ref = count << 28 | index, sibling pairs adjacent; triOrder = original triangle id per leaf slot) with the same
 // order as the kernels -- both children of a pair tested per step, near child first, far child stacked, boxes
-// culled against the closest accepted hit -- and counts box tests and triangle tests.  The kernels use the
+// culled against the closest accepted hit -- and counts box tests and triangle tests.  anyHit: 0 closest hit; 1 first
+// hit, near child first; 2 first hit, children in storage order (what the kernels do when the scene is in LDS).  The kernels use the
 // hardware reciprocal for the slab test, this uses 1/x, so counts agree to a small fraction of a percent.
 // out = {nodes tested, triangles tested}; triId (optional) receives the accepted triangle (-1 = none).
 void orc_bvh_count(void* h, const float* nodes8, uint32_t rootRef, const uint32_t* triOrder, const float* rays6,
@@ -823,6 +824,7 @@ void orc_bvh_count(void* h, const float* nodes8, uint32_t rootRef, const uint32_
       for (int k = 0; k < 3; k++) { float a = std::fmaf(n[k], inv[k], oi[k]), b = std::fmaf(n[4 + k], inv[k], oi[k]); lo[k] = fminf(a, b); hi[k] = fmaxf(a, b); }
       tn = fmaxf(fmaxf(lo[0], lo[1]), fmaxf(lo[2], 0.0f));
       float tf = fminf(fminf(hi[0], hi[1]), hi[2]) * 1.0000005f;
+      if (anyHit) return !(tn > tf);
       return tn <= fminf(tf, bt);
     };
     while (live && !done) {
@@ -830,7 +832,7 @@ void orc_bvh_count(void* h, const float* nodes8, uint32_t rootRef, const uint32_
         const float* n0 = nodes8 + (size_t)ref * 16; const float* n1 = n0 + 8; cN += 2;
         float tn0, tn1; bool h0 = slab(n0, tn0), h1 = slab(n1, tn1);
         uint32_t r0, r1; std::memcpy(&r0, n0 + 3, 4); std::memcpy(&r1, n1 + 3, 4);
-        if (h0 && h1) { bool sw = tn1 < tn0; stack[sp++] = sw ? r0 : r1; ref = sw ? r1 : r0; }
+        if (h0 && h1) { bool sw = anyHit != 2 && tn1 < tn0; stack[sp++] = sw ? r0 : r1; ref = sw ? r1 : r0; }
         else if (h0 || h1) ref = h0 ? r0 : r1;
         else { if (sp == 0) { live = false; break; } ref = stack[--sp]; }
       }

@@ -716,7 +716,7 @@ int ptgpu_scene_hits_nothing(PtHandle* h, const float* rays6, uint32_t count, ui
     if (!count) return;
     DevBuf dr, dout; dr.alloc((size_t)count * 24); dout.alloc(count);
     HIPCHECK(hipMemcpyAsync(dr.p, rays6, (size_t)count * 24, hipMemcpyHostToDevice, h->stream));
-    launchHitsNothing(makeLaunchCfg(h), h->dsc, makeDevCfg(h), dr.as<float>(), count, dout.as<uint8_t>());
+    launchHitsNothing(makeLaunchCfg(h), h->dsc, makeDevCfg(h), dr.as<float>(), count, dout.as<uint8_t>(), h->bStats.as<unsigned long long>());
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(out, dout.p, count, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));

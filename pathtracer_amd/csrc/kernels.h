@@ -178,7 +178,7 @@ void launchTraceRays(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg,
 void launchTraceTex(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const float* tex6, const float* rays6,
                     uint32_t count, bool ignoreBackfaces, int32_t* result, int32_t* triId, float* t, float* tc2);
 void launchHitsNothing(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const float* rays6, uint32_t count,
-                       uint8_t* out);
+                       uint8_t* out, unsigned long long* stats);
 void launchTonemap(const LaunchCfg& lc, const float4* acc, uint32_t pixelOffset, uint32_t count, uint8_t* rgb);
 void launchRngStream(const LaunchCfg& lc, uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n,
                      uint32_t* out);

@@ -83,9 +83,10 @@ __device__ __forceinline__ uint32_t octantOf(const RayInv& r) {
   return (__float_as_uint(r.ix) >> 31) | ((__float_as_uint(r.iy) >> 31) << 1) | ((__float_as_uint(r.iz) >> 31) << 2);
 }
 // Entry distance of the ray into the box [mn, mx]; hit iff tn <= min(far * (1 + 2 ulp), tmax).
+// UNBOUNDED: tmax is not looked at (it is FLT_MAX).
 // OCT < 0: any direction (near / far plane of each axis by min / max).  OCT = 0..7: the direction's octant is known
 // at compile time, so is which plane of each axis is the near one, and the six min / max disappear.
-template <int OCT = -1>
+template <int OCT = -1, bool UNBOUNDED = false>
 __device__ __forceinline__ bool slab(const RayInv& r, float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
                                      float tmax, float& tn) {
   float p0x = fmaf(mnx, r.ix, r.ox), p1x = fmaf(mxx, r.ix, r.ox);
@@ -103,6 +104,7 @@ __device__ __forceinline__ bool slab(const RayInv& r, float mnx, float mny, floa
   }
   tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
   float tf = fminf(fminf(fx, fy), fz) * 1.0000005f;
+  if constexpr (UNBOUNDED) return !(tn > tf);      // any-hit rays have no far limit; a NaN keeps the box, as fminf does
   return tn <= fminf(tf, tmax);
 }
 
@@ -177,17 +179,20 @@ __device__ __forceinline__ uint32_t popRef(const uint32_t* stack, int& sp) {
   return r;
 }
 
-template <bool LDSS, int OCT>
+template <bool LDSS, int OCT, bool UNBOUNDED = false>
 __device__ __forceinline__ uint32_t stepDown(const DevScene& sc, const RayInv& ri, float tmax, uint32_t ref, uint32_t* stack, int& sp) {
   uint32_t b = ref * 4;
   float4 a0 = ldNode<LDSS>(sc, b), a1 = ldNode<LDSS>(sc, b + 1);
   float4 b0 = ldNode<LDSS>(sc, b + 2), b1 = ldNode<LDSS>(sc, b + 3);
   keepW<LDSS>(a1, b1);
   float tn0, tn1;
-  bool h0 = slab<OCT>(ri, a0.x, a0.y, a0.z, a1.x, a1.y, a1.z, tmax, tn0);
-  bool h1 = slab<OCT>(ri, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, tmax, tn1);
+  bool h0 = slab<OCT, UNBOUNDED>(ri, a0.x, a0.y, a0.z, a1.x, a1.y, a1.z, tmax, tn0);
+  bool h1 = slab<OCT, UNBOUNDED>(ri, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, tmax, tn1);
   uint32_t r0 = f2u(a0.w), r1 = f2u(b0.w);
-  bool sw = h1 && (!h0 || tn1 < tn0);
+  // any-hit rays in an LDS-resident scene take the children in storage order: no occluder is nearer than another to
+  // a query that stops at the first, and the comparison and selects cost more than the ordering saves (-2 %); with
+  // the scene in HBM every extra step is a memory round trip and near-first stays ahead (+2 %)
+  bool sw = (UNBOUNDED && LDSS) ? (h1 && !h0) : (h1 && (!h0 || tn1 < tn0));
   uint32_t nearRef = sw ? r1 : r0, farRef = sw ? r0 : r1;
   if (h0 && h1) stack[sp++] = farRef;  // (storing unconditionally above the top was measured: 20 % slower)
   if (h0 || h1) return nearRef;
@@ -217,7 +222,7 @@ __device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri
   uint32_t ref = sc.rootRef;
   if constexpr (!POSTPONE) {
     for (;;) {
-      while (isInternal(ref)) { if (COUNT) cN += 2; ref = stepDown<LDSS, OCT>(sc, ri, h.t, ref, stack, sp); }
+      while (isInternal(ref)) { if (COUNT) cN += 2; ref = stepDown<LDSS, OCT, ANY>(sc, ri, h.t, ref, stack, sp); }
       if (ref == PT_NONE) break;
       uint32_t cnt = ref >> BVH_COUNT_SHIFT, first = ref & BVH_INDEX_MASK;
       for (uint32_t i = 0; i < cnt; i++) {
@@ -232,7 +237,7 @@ __device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri
     if (isLeaf(ref)) { leaf = ref; ref = PT_NONE; }                        // the root is a leaf
     for (;;) {
       while (isInternal(ref)) {
-        ref = stepDown<LDSS, OCT>(sc, ri, h.t, ref, stack, sp);
+        ref = stepDown<LDSS, OCT, ANY>(sc, ri, h.t, ref, stack, sp);
         if (leaf == PT_NONE && isLeaf(ref)) { leaf = ref; ref = sp ? popRef(stack, sp) : PT_NONE; }
         if (!__any(leaf == PT_NONE && ref != PT_NONE)) break;
       }
@@ -644,7 +649,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_occluded(DevScene sc, float eps, V3 sunRad
       // parallel and walk the tree together, and mixing them with sky rays breaks that up.)
       bool vSun = false, vSky = false;
       Hit h;
-      if (eSun) vSun = !traverse<true, LDSS, COUNT>(sc, xyz(ro), xyz(a), eps, h, cN, cT);
+      if (eSun) vSun = !traverse<true, LDSS, COUNT, !COUNT>(sc, xyz(ro), xyz(a), eps, h, cN, cT);   // one octant: see traverse
       if (eSky) vSky = !traverse<true, LDSS, COUNT>(sc, xyz(ro), xyz(b), eps, h, cN, cT);
       if (direct || vSun || vSky) {
         float4 x = shX[e];
@@ -924,16 +929,17 @@ __global__ void PT_TRAVERSAL_BOUNDS k_trace_tex(DevScene sc, float eps, const fl
   }
 }
 
-template <bool LDSS>
+template <bool LDSS, bool COUNT>
 __global__ void PT_TRAVERSAL_BOUNDS k_hits_nothing(DevScene sc, float eps, const float* __restrict__ rays6, uint32_t count,
-                                                       uint8_t* out) {
+                                                       uint8_t* out, unsigned long long* stats) {
   stageScene<LDSS>(sc);
   uint32_t cN = 0, cT = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     const float* r = rays6 + 6 * (size_t)i;
     Hit h;
-    out[i] = traverse<true, LDSS, false, false>(sc, v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]), eps, h, cN, cT) ? 0 : 1;
+    out[i] = traverse<true, LDSS, COUNT, false>(sc, v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]), eps, h, cN, cT) ? 0 : 1;
   }
+  flushCounts<COUNT>(stats, STAT_NODES_ANY, cN, cT);
 }
 
 // drawScreen's scalar path, main.d:82-95
@@ -1085,10 +1091,10 @@ void launchTraceTex(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, 
   else launchTraceTexT<true>(lc, sc, cfg, tex6, rays6, count, result, triId, t, tc2);
 }
 
-void launchHitsNothing(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const float* rays6, uint32_t count, uint8_t* out) {
+void launchHitsNothing(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const float* rays6, uint32_t count, uint8_t* out,
+                       unsigned long long* stats) {
   Geo g = traversalGeo(lc, sc, count);
-  if (sc.ldsBytes) { allowLds(lc, (const void*)k_hits_nothing<true>, g.lds); hipLaunchKernelGGL(k_hits_nothing<true>, g.grid, g.block, g.lds, lc.stream, sc, cfg.eps, rays6, count, out); }
-  else hipLaunchKernelGGL(k_hits_nothing<false>, g.grid, g.block, 0, lc.stream, sc, cfg.eps, rays6, count, out);
+  PT_DISPATCH_LC(k_hits_nothing, sc, cfg.eps, rays6, count, out, stats);
 }
 
 void launchTonemap(const LaunchCfg& lc, const float4* acc, uint32_t pixelOffset, uint32_t count, uint8_t* rgb) {

@@ -282,3 +282,13 @@ def test_visit_counters_match_cpu_restatement_of_the_traversal(require_gpu, flat
     n_nodes, n_tris, _ = o.bvh_count(nodes, root, order, o.view_rays(0, W * H))
     assert abs(st.nodesClosest - n_nodes) <= 1e-3 * n_nodes
     assert abs(st.trisClosest - n_tris) <= 1e-3 * n_tris
+    # any-hit queries: children in storage order when the scene is in LDS, near child first when it is not
+    rays = random_rays(flats[name], 40000, 3)
+    for flags, order_rule in ((P.PT_FLAG_COUNT_VISITS, 2), (P.PT_FLAG_COUNT_VISITS | P.PT_FLAG_NO_LDS_SCENE, 1)):
+        pa = make_tracer(name, W, H, flags=flags)
+        nodes, order = pa.get_bvh()
+        pa.reset_stats(); free = pa.hitsNothing(rays)
+        st = pa.stats()
+        n_nodes, n_tris, tri = o.bvh_count(nodes, root, order, rays, any_hit=order_rule)
+        assert np.array_equal(free, tri < 0)
+        assert abs(st.nodesAny - n_nodes) <= 1e-3 * n_nodes and abs(st.trisAny - n_tris) <= 1e-3 * n_tris
