@@ -124,13 +124,13 @@ PT_HD float interpolateComponent(float u, float v, float val0, float val1, float
 
 // rendering.d:309-314
 PT_HD V3 angleToLocalDirection(float phi, float psi) {
-  float cosPhi = cosf(phi);
-  return v3(cosf(psi) * cosPhi, sinf(psi) * cosPhi, sinf(phi));
+  float sinPhi, cosPhi, sinPsi, cosPsi;                      // one argument reduction per angle instead of two
+  sincosf(phi, &sinPhi, &cosPhi); sincosf(psi, &sinPsi, &cosPsi);
+  return v3(cosPsi * cosPhi, sinPsi * cosPhi, sinPhi);
 }
 // rendering.d:316-330
 PT_HD V3 angleToDirection(float phi, float psi, V3 normal) {
-  float cosPhi = cosf(phi);
-  V3 localDir = v3(cosf(psi) * cosPhi, sinf(psi) * cosPhi, sinf(phi));
+  V3 localDir = angleToLocalDirection(phi, psi);
   V3 up = normal, dir = v3(1, 0, 0);
   if (fabsf(dot(dir, up)) > 0.9f) dir = v3(0, 1, 0);
   V3 right = normalized(cross(up, dir));
