@@ -240,8 +240,8 @@ void ensureWavefront(PtHandle* h) {
   const PtConfig& c = h->cfg;
   // Large batches: every launch ends with a tail in which the last waves finish alone, and a batch is ~10 launches.
   // Measured on the 1080p teapot frame (ms per 256 spp): 4 M slots 70, 16 M 31.6, 32 M 28.0, 64 M 26.8, 128 M 26.4.
-  // HBM has room: 160 B per slot in mode 0 with two shadow kinds (64 M slots = 10.7 GB), ~1.06 KB in mode 1 with
-  // 5 indirect chains (32 M slots = 34 GB; chest1 1080p mode 1, ms per 64 spp: 8 M 28.1, 32 M 17.0, 64 M 15.1).
+  // HBM has room: 128 B per slot in mode 0 without light groups (64 M slots = 8.6 GB), ~0.9 KB in mode 1 with
+  // 5 indirect chains (32 M slots = 30 GB; chest1 1080p mode 1, ms per 64 spp: 8 M 28.1, 32 M 17.0, 64 M 15.1).
   uint64_t want = c.batchSlots ? c.batchSlots : (c.mode == 1 ? (1u << 25) : (1u << 26));
   uint64_t frame = (uint64_t)c.width * c.height;
   // no point in more slots than 64 samples of the whole frame; a multiple of 64 * PT_SEGS so that every block-task's
