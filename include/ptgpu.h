@@ -117,7 +117,8 @@ int ptgpu_get_scene(PtHandle* h, float* v, float* n, uint32_t* matIdx, PtMateria
 /* Light table as built by loadScene: for group g, up to cap rows of 11 floats (v0,e1,e2,area,probability). */
 int ptgpu_get_light_group(PtHandle* h, uint32_t g, float* rows11, uint32_t cap, uint32_t* count, float* totalArea);
 /* Flattened BVH: nodes = numNodes x 8 floats (min.xyz, ref, max.xyz, unused), refs as uint32 bit patterns;
- * triOrder = numTriangles original triangle ids in leaf order. */
+ * triOrder = numTriangles original triangle ids in leaf order.  When the scene is traversed from global memory
+ * (PtStats.sceneInLds == 0) the boxes are the ones the kernels use: rounded outwards to a 16-bit grid over the root box. */
 int ptgpu_get_bvh(PtHandle* h, float* nodes8, uint32_t* triOrder);
 
 /* Exactly Camera's private state (camera.d:11-12) ... */

@@ -210,7 +210,15 @@ void uploadScene(PtHandle* h) {
     HIPCHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
   };
   HIPCHECK(hipStreamSynchronize(h->stream));
-  up(h->dNodes, bvh.nodes.data(), bvh.nodes.size() * 4);
+  size_t ldsNeed = ((size_t)2 * bvh.numNodes + (size_t)3 * NT) * 16;
+  DevScene& d = h->dsc;
+  d.ldsBytes = (!(h->cfg.flags & PT_FLAG_NO_LDS_SCENE) && ldsNeed <= 156 * 1024) ? (uint32_t)ldsNeed : 0;
+  if (d.ldsBytes) up(h->dNodes, bvh.nodes.data(), bvh.nodes.size() * 4);
+  else {                   // traversal from global memory reads the 16-byte quantised nodes
+    std::vector<uint32_t> q((size_t)std::max(1u, bvh.numNodes) * 4, 0u);
+    quantizeNodes(bvh.nodes.data(), bvh.numNodes, q.data(), d.qBase, d.qScale);
+    up(h->dNodes, q.data(), q.size() * 4);
+  }
   up(h->dTris, tris.data(), tris.size() * 4);
   up(h->dNrm, nrm.data(), nrm.size() * 4);
   up(h->dMats, mats.data(), mats.size() * 4);
@@ -219,16 +227,14 @@ void uploadScene(PtHandle* h) {
   up(h->dLightCount, lc.data(), lc.size() * 4);
   up(h->dLightArea, la.data(), la.size() * 4);
 
-  DevScene& d = h->dsc;
-  d.nodes = h->dNodes.as<float4>(); d.tris = h->dTris.as<float4>(); d.nrm = h->dNrm.as<float4>();
+  d.nodes = d.ldsBytes ? h->dNodes.as<float4>() : nullptr; d.qnodes = d.ldsBytes ? nullptr : h->dNodes.as<uint4>();
+  d.tris = h->dTris.as<float4>(); d.nrm = h->dNrm.as<float4>();
   d.mats = h->dMats.as<float4>(); d.lights = h->dLights.as<float>();
   d.lightFirst = h->dLightFirst.as<uint32_t>(); d.lightCount = h->dLightCount.as<uint32_t>();
   d.lightArea = h->dLightArea.as<float>();
   d.numNodes = bvh.numNodes; d.numTris = NT; d.numOrigTris = T; d.rootRef = bvh.rootRef;
   d.numLightGroups = (uint32_t)lt.numGroups();
   for (int k = 0; k < 3; k++) { h->box.mn[k] = bvh.nodes[k]; h->box.mx[k] = bvh.nodes[4 + k]; }   // node 0 = root
-  size_t ldsNeed = ((size_t)2 * bvh.numNodes + (size_t)3 * NT) * 16;
-  d.ldsBytes = (!(h->cfg.flags & PT_FLAG_NO_LDS_SCENE) && ldsNeed <= 156 * 1024) ? (uint32_t)ldsNeed : 0;
   h->haveScene = true;
   h->st.numTriangles = T; h->st.numNodes = bvh.numNodes; h->st.bvhDepth = bvh.depth;
   h->st.numLightGroups = d.numLightGroups; h->st.sceneInLds = d.ldsBytes ? 1 : 0;
@@ -528,7 +534,12 @@ int ptgpu_get_bvh(PtHandle* h, float* nodes8, uint32_t* triOrder) {
   return guarded([&]() {
     if (!h) fail(PT_E_INVALID, "null handle");
     if (!h->haveScene) fail(PT_E_STATE, "no scene");
-    if (nodes8) std::memcpy(nodes8, h->bvh.nodes.data(), h->bvh.nodes.size() * 4);
+    if (nodes8 && h->cfg.device >= 0 && h->dsc.ldsBytes == 0) {       // the boxes the kernels traverse: on the grid
+      std::vector<uint32_t> q((size_t)std::max(1u, h->bvh.numNodes) * 4, 0u);
+      float base[3], scale[3];
+      quantizeNodes(h->bvh.nodes.data(), h->bvh.numNodes, q.data(), base, scale);
+      dequantizeNodes(q.data(), h->bvh.numNodes, base, scale, nodes8);
+    } else if (nodes8) std::memcpy(nodes8, h->bvh.nodes.data(), h->bvh.nodes.size() * 4);
     if (triOrder) std::memcpy(triOrder, h->bvh.triOrder.data(), h->bvh.triOrder.size() * 4);
   });
 }

@@ -156,4 +156,47 @@ void buildBvh(const float* v, uint32_t T, uint32_t maxLeaf, Bvh& out) {
   out.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
+void quantizeNodes(const float* nodes, uint32_t numNodes, uint32_t* out, float qBase[3], float qScale[3]) {
+  double cell[3], base[3];
+  for (int k = 0; k < 3; k++) {
+    double lo = numNodes ? nodes[k] : 0.0, hi = numNodes ? nodes[4 + k] : 0.0;
+    if (!(hi >= lo)) { lo = 0.0; hi = 0.0; }                            // empty scene: the root box is inverted
+    cell[k] = std::max((hi - lo) / 65529.0, 1e-30);                     // three spare cells at either end
+    base[k] = lo - 3.0 * cell[k];
+    qBase[k] = (float)base[k]; qScale[k] = (float)cell[k];
+  }
+  for (uint32_t n = 0; n < numNodes; n++) {
+    const float* p = nodes + (size_t)n * 8;
+    uint32_t w[3];
+    for (int k = 0; k < 3; k++) {
+      float mn = p[k], mx = p[4 + k];
+      long qlo, qhi;
+      if (!(mx >= mn)) { qlo = 65535; qhi = 0; }                        // an empty box (padding node) stays empty
+      else {
+        qlo = (long)std::floor(((double)mn - base[k]) / cell[k]) - 1;
+        qhi = (long)std::ceil(((double)mx - base[k]) / cell[k]) + 1;
+        qlo = std::min(std::max(qlo, 0l), 65535l); qhi = std::min(std::max(qhi, 0l), 65535l);
+        // containment under the float evaluation the kernels and dequantizeNodes use
+        while (qlo > 0 && !(fmaf((float)qlo, qScale[k], qBase[k]) <= mn)) qlo--;
+        while (qhi < 65535 && !(fmaf((float)qhi, qScale[k], qBase[k]) >= mx)) qhi++;
+      }
+      w[k] = (uint32_t)qlo | ((uint32_t)qhi << 16);
+    }
+    uint32_t ref; std::memcpy(&ref, p + 3, 4);
+    uint32_t* o = out + (size_t)n * 4;
+    o[0] = w[0]; o[1] = w[1]; o[2] = w[2]; o[3] = ref;
+  }
+}
+
+void dequantizeNodes(const uint32_t* q, uint32_t numNodes, const float qBase[3], const float qScale[3], float* nodes) {
+  for (uint32_t n = 0; n < numNodes; n++) {
+    const uint32_t* w = q + (size_t)n * 4; float* p = nodes + (size_t)n * 8;
+    for (int k = 0; k < 3; k++) {
+      p[k] = fmaf((float)(w[k] & 0xFFFFu), qScale[k], qBase[k]);
+      p[4 + k] = fmaf((float)(w[k] >> 16), qScale[k], qBase[k]);
+    }
+    std::memcpy(p + 3, w + 3, 4); p[7] = 0.0f;
+  }
+}
+
 }  // namespace pt

@@ -24,6 +24,14 @@ struct Bvh {
   double buildSeconds = 0;
 };
 
+// The tree for traversal from global memory: 16 B per node instead of 32.  Box planes on a 16-bit grid over the root
+// box (node 0), per node 4 words: x: min | max << 16, y and z likewise, w: ref.  plane = fmaf(q, qScale, qBase) in
+// float, and every quantised box contains its original under exactly that evaluation (quantizeNodes rounds outwards,
+// one grid cell beyond the float rounding of the evaluation).  out = numNodes x 4 words.
+void quantizeNodes(const float* nodes, uint32_t numNodes, uint32_t* out, float qBase[3], float qScale[3]);
+// The boxes the quantised tree stands for, in the layout of Bvh::nodes.
+void dequantizeNodes(const uint32_t* q, uint32_t numNodes, const float qBase[3], const float qScale[3], float* nodes);
+
 // v = T x 9 floats (v0, v1, v2).  Binned-SAH top-down build, leaves of at most maxLeaf triangles.
 void buildBvh(const float* v, uint32_t T, uint32_t maxLeaf, Bvh& out);
 

@@ -27,7 +27,11 @@ PT_HD uint32_t fdiv(const FastDiv& f, uint32_t n) {
 // Everything the traversal and shading kernels read.  All arrays live in HBM; when ldsBytes != 0 the
 // traversal kernels copy nodes + tris into LDS once per workgroup and traverse from there.
 struct DevScene {
-  const float4* nodes;        // 2 x float4 per node: (min.xyz, ref) (max.xyz, 0); sibling pairs adjacent
+  const float4* nodes;        // 2 x float4 per node: (min.xyz, ref) (max.xyz, 0); sibling pairs adjacent.  Only
+                              // present when ldsBytes != 0.
+  const uint4* qnodes;        // the same tree for traversal from global memory (ldsBytes == 0), 16 B per node: box
+                              // planes on a 16-bit grid over the root box, x: min | max << 16, y, z likewise, w: ref.
+                              // plane = qBase + q * qScale, rounded outwards: the boxes only grow
   const float4* tris;         // 3 x float4 per leaf-order triangle: (v0, origId) (v2-v0, 0) (v1-v0, 0)
   const float4* nrm;          // 3 x float4 per ORIGINAL triangle: (n0, matIdx) (n1, 0) (n2, 0)
   const float4* mats;         // (emissive, r, g, b)                                   rendering.d:33-37
@@ -37,6 +41,7 @@ struct DevScene {
   const float* lightArea;     // g_totalLightSourceArea
   uint32_t numNodes, numTris, numOrigTris, rootRef, numLightGroups;
   uint32_t ldsBytes;          // 0 => traverse from global memory
+  float qBase[3], qScale[3];
 };
 
 // The root box of the BVH.  A view ray that misses it cannot hit anything; raygen answers it without a traversal.

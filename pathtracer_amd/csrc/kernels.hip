@@ -46,7 +46,8 @@ __device__ __forceinline__ V3 xyz(float4 a) { return v3(a.x, a.y, a.z); }
 __device__ __forceinline__ float4 f4(V3 a, float w) { return make_float4(a.x, a.y, a.z, w); }
 
 template <bool LDSS> __device__ __forceinline__ float4 ldNode(const DevScene& sc, uint32_t i) {
-  if constexpr (LDSS) return g_lds[i]; else return sc.nodes[i];
+  static_assert(LDSS, "from global memory the tree is read through DevScene::qnodes");
+  return g_lds[i];
 }
 template <bool LDSS> __device__ __forceinline__ float4 ldTri(const DevScene& sc, uint32_t i) {
   if constexpr (LDSS) return g_lds[2 * sc.numNodes + i]; else return sc.tris[i];
@@ -181,14 +182,27 @@ __device__ __forceinline__ uint32_t popRef(const uint32_t* stack, int& sp) {
 
 template <bool LDSS, int OCT, bool UNBOUNDED = false>
 __device__ __forceinline__ uint32_t stepDown(const DevScene& sc, const RayInv& ri, float tmax, uint32_t ref, uint32_t* stack, int& sp) {
-  uint32_t b = ref * 4;
-  float4 a0 = ldNode<LDSS>(sc, b), a1 = ldNode<LDSS>(sc, b + 1);
-  float4 b0 = ldNode<LDSS>(sc, b + 2), b1 = ldNode<LDSS>(sc, b + 3);
-  keepW<LDSS>(a1, b1);
   float tn0, tn1;
-  bool h0 = slab<OCT, UNBOUNDED>(ri, a0.x, a0.y, a0.z, a1.x, a1.y, a1.z, tmax, tn0);
-  bool h1 = slab<OCT, UNBOUNDED>(ri, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, tmax, tn1);
-  uint32_t r0 = f2u(a0.w), r1 = f2u(b0.w);
+  bool h0, h1;
+  uint32_t r0, r1;
+  if constexpr (LDSS) {
+    uint32_t b = ref * 4;
+    float4 a0 = ldNode<LDSS>(sc, b), a1 = ldNode<LDSS>(sc, b + 1);
+    float4 b0 = ldNode<LDSS>(sc, b + 2), b1 = ldNode<LDSS>(sc, b + 3);
+    keepW<LDSS>(a1, b1);
+    h0 = slab<OCT, UNBOUNDED>(ri, a0.x, a0.y, a0.z, a1.x, a1.y, a1.z, tmax, tn0);
+    h1 = slab<OCT, UNBOUNDED>(ri, b0.x, b0.y, b0.z, b1.x, b1.y, b1.z, tmax, tn1);
+    r0 = f2u(a0.w); r1 = f2u(b0.w);
+  } else {
+    // 32 B per sibling pair instead of 64: the vector-memory address unit, which bounds this path, is busy 16 cycles
+    // per 16-byte-per-lane load whatever the addresses.  ri maps grid coordinates straight to ray parameters.
+    uint4 a = sc.qnodes[ref * 2], b = sc.qnodes[ref * 2 + 1];
+    h0 = slab<OCT, UNBOUNDED>(ri, (float)(a.x & 0xFFFFu), (float)(a.y & 0xFFFFu), (float)(a.z & 0xFFFFu),
+                              (float)(a.x >> 16), (float)(a.y >> 16), (float)(a.z >> 16), tmax, tn0);
+    h1 = slab<OCT, UNBOUNDED>(ri, (float)(b.x & 0xFFFFu), (float)(b.y & 0xFFFFu), (float)(b.z & 0xFFFFu),
+                              (float)(b.x >> 16), (float)(b.y >> 16), (float)(b.z >> 16), tmax, tn1);
+    r0 = a.w; r1 = b.w;
+  }
   // any-hit rays in an LDS-resident scene take the children in storage order: no occluder is nearer than another to
   // a query that stops at the first, and the comparison and selects cost more than the ordering saves (-2 %); with
   // the scene in HBM every extra step is a memory round trip and near-first stays ahead (+2 %)
@@ -261,6 +275,11 @@ __device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri
 template <bool ANY, bool LDSS, bool COUNT, bool BY_OCTANT = !COUNT && !ANY, bool BOTH = false>
 __device__ __forceinline__ bool traverse(const DevScene& sc, V3 o, V3 d, float eps, Hit& h, uint32_t& cN, uint32_t& cT) {
   RayInv ri = makeRayInv(o, d);
+  if constexpr (!LDSS) {     // box planes come as grid coordinates q: plane = qBase + q * qScale
+    ri.ox = fmaf(sc.qBase[0], ri.ix, ri.ox); ri.ix = sc.qScale[0] * ri.ix;
+    ri.oy = fmaf(sc.qBase[1], ri.iy, ri.oy); ri.iy = sc.qScale[1] * ri.iy;
+    ri.oz = fmaf(sc.qBase[2], ri.iz, ri.oz); ri.iz = sc.qScale[2] * ri.iz;
+  }
   if constexpr (BY_OCTANT) {
     uint32_t oct = octantOf(ri), o0 = __builtin_amdgcn_readfirstlane(oct);
     if (__all(oct == o0)) {
