@@ -233,7 +233,7 @@ void uploadScene(PtHandle* h) {
   d.lightFirst = h->dLightFirst.as<uint32_t>(); d.lightCount = h->dLightCount.as<uint32_t>();
   d.lightArea = h->dLightArea.as<float>();
   d.numNodes = bvh.numNodes; d.numTris = NT; d.numOrigTris = T; d.rootRef = bvh.rootRef;
-  d.numLightGroups = (uint32_t)lt.numGroups();
+  d.numLightGroups = (uint32_t)lt.numGroups(); d.numMats = (uint32_t)fs.mats.size(); d.numLightTris = (uint32_t)lt.tris.size();
   for (int k = 0; k < 3; k++) { h->box.mn[k] = bvh.nodes[k]; h->box.mx[k] = bvh.nodes[4 + k]; }   // node 0 = root
   h->haveScene = true;
   h->st.numTriangles = T; h->st.numNodes = bvh.numNodes; h->st.bvhDepth = bvh.depth;

@@ -39,7 +39,7 @@ struct DevScene {
   const uint32_t* lightFirst; // per light group
   const uint32_t* lightCount;
   const float* lightArea;     // g_totalLightSourceArea
-  uint32_t numNodes, numTris, numOrigTris, rootRef, numLightGroups;
+  uint32_t numNodes, numTris, numOrigTris, rootRef, numLightGroups, numMats, numLightTris;
   uint32_t ldsBytes;          // 0 => traverse from global memory
   float qBase[3], qScale[3];
 };
@@ -148,6 +148,13 @@ struct Wavefront {
 
 enum { STAT_RAYS_LIGHT = 0, STAT_RAYS_INDIRECT, STAT_RAYS_OCCL, STAT_NODES_CLOSEST, STAT_TRIS_CLOSEST,
        STAT_NODES_ANY, STAT_TRIS_ANY, STAT_RAYS_CULLED, STAT_COUNT };
+
+// Shading tables (vertex normals, materials, light triangles, light groups) small enough for every shade workgroup
+// to keep a copy in LDS: bytes of that copy, or 0 when they are read from global memory.
+inline uint32_t shadeTableBytes(const DevScene& sc) {
+  uint64_t b = ((uint64_t)3 * sc.numOrigTris + sc.numMats + (uint64_t)3 * sc.numLightTris) * 16 + (uint64_t)2 * sc.numLightGroups * 4;
+  return b <= 24576 ? (uint32_t)b : 0u;
+}
 
 // Whether the sun/sky kernel stores L of a vertex outright instead of adding to it: view-ray hits of a scene in which
 // no light-group kernel adds to L before it.

@@ -593,6 +593,40 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend_primary(DevScene sc, DevCfg cfg, Pi
   flushCounts<COUNT>(stats, STAT_NODES_CLOSEST, cN, cT);
 }
 
+// The tables shading reads per hit.  LDST: the workgroup's copy in LDS (kernels.h: shadeTableBytes) -- an iteration
+// of shade is a chain of dependent reads (hit -> normals -> material -> light group -> light triangle), and at four
+// waves per SIMD the chain's latency, not bandwidth, is what a launch on a small scene waits for.
+template <bool LDST> struct ShadeTables {
+  const DevScene& sc;
+  uint32_t base;              // first float4 of the copy in the workgroup's dynamic LDS
+  __device__ __forceinline__ uint32_t oMat() const { return base + 3 * sc.numOrigTris; }
+  __device__ __forceinline__ uint32_t oLight() const { return oMat() + sc.numMats; }
+  __device__ __forceinline__ uint32_t oGroup() const { return oLight() + 3 * sc.numLightTris; }
+  __device__ __forceinline__ void stage() const {
+    if constexpr (LDST) {
+      for (uint32_t i = threadIdx.x; i < 3 * sc.numOrigTris; i += blockDim.x) g_lds[base + i] = sc.nrm[i];
+      for (uint32_t i = threadIdx.x; i < sc.numMats; i += blockDim.x) g_lds[oMat() + i] = sc.mats[i];
+      float* lt = (float*)(g_lds + oLight());
+      for (uint32_t i = threadIdx.x; i < 12 * sc.numLightTris; i += blockDim.x) lt[i] = sc.lights[i];
+      uint32_t* gr = (uint32_t*)(g_lds + oGroup());
+      for (uint32_t i = threadIdx.x; i < sc.numLightGroups; i += blockDim.x) {
+        gr[i] = sc.lightFirst[i]; gr[sc.numLightGroups + i] = sc.lightCount[i];
+      }
+    }
+  }
+  __device__ __forceinline__ float4 nrm(uint32_t i) const { if constexpr (LDST) return g_lds[base + i]; else return sc.nrm[i]; }
+  __device__ __forceinline__ float4 mat(uint32_t i) const { if constexpr (LDST) return g_lds[oMat() + i]; else return sc.mats[i]; }
+  __device__ __forceinline__ float light(uint32_t t, uint32_t k) const {
+    if constexpr (LDST) return ((const float*)(g_lds + oLight()))[t * 12 + k]; else return sc.lights[(size_t)t * 12 + k];
+  }
+  __device__ __forceinline__ uint32_t lightFirst(uint32_t li) const {
+    if constexpr (LDST) return ((const uint32_t*)(g_lds + oGroup()))[li]; else return sc.lightFirst[li];
+  }
+  __device__ __forceinline__ uint32_t lightCount(uint32_t li) const {
+    if constexpr (LDST) return ((const uint32_t*)(g_lds + oGroup()))[sc.numLightGroups + li]; else return sc.lightCount[li];
+  }
+};
+
 // ------------------------------------------------------------------------------------------------ connect
 // Light-sample rays: Scene.trace + the body of `if(distanceY > lightDistance - FloatEpsilon)`, rendering.d:414-425.
 // At most one entry per lane slot and launch, so the read-modify-write of Lacc needs no atomics and the
@@ -729,7 +763,9 @@ __device__ __forceinline__ void emitShadow(ShadeCtx& cx, int kind, bool emit, V3
 // computeLdirect up to (not including) the trace calls, rendering.d:396-462: emits one shadow ray per light group and
 // one entry for the sun and sky rays together (envX: what the kernel that traces them needs besides, see k_occluded).
 // Returns whether the lane emitted that entry.
-__device__ __forceinline__ bool directLight(ShadeCtx& cx, bool active, Rng& g, V3 x, V3 normalX, V3 Tw, float4 envX, uint32_t laneSlot) {
+template <bool LDST>
+__device__ __forceinline__ bool directLight(ShadeCtx& cx, const ShadeTables<LDST>& tb, bool active, Rng& g, V3 x, V3 normalX, V3 Tw, float4 envX,
+                                            uint32_t laneSlot) {
   const DevScene& sc = cx.sc; const DevCfg& cfg = cx.cfg;
   float eps = cfg.eps;
   int kind = 0;
@@ -738,18 +774,19 @@ __device__ __forceinline__ bool directLight(ShadeCtx& cx, bool active, Rng& g, V
       bool emit = false; V3 phi = v3(0, 0, 0); float lightDistance = 0.0f, ndot = 0.0f;
       if (active) {
         // pickRandomLightPoint, rendering.d:164-193
-        uint32_t first = sc.lightFirst[li], cnt = sc.lightCount[li];
+        uint32_t first = tb.lightFirst(li), cnt = tb.lightCount(li);
         float a = g.uniform(0.0f, 1.0f);
         uint32_t chosen = cnt - 1;
         for (uint32_t j = 0; j < cnt; j++) {
-          float prob = sc.lights[(first + j) * 12 + 10];
+          float prob = tb.light(first + j, 10);
           if (prob > a) { chosen = j; break; }
           a -= prob;
         }
-        const float* lt = sc.lights + (size_t)(first + chosen) * 12;
+        uint32_t lt = first + chosen;
         float u, v;
         do { u = g.uniform(0.0f, 1.0f); v = g.uniform(0.0f, 1.0f); } while (!(u + v <= 1.0f));
-        V3 y = v3(lt[0], lt[1], lt[2]) + v3(lt[3], lt[4], lt[5]) * v + v3(lt[6], lt[7], lt[8]) * u;
+        V3 y = v3(tb.light(lt, 0), tb.light(lt, 1), tb.light(lt, 2)) + v3(tb.light(lt, 3), tb.light(lt, 4), tb.light(lt, 5)) * v +
+               v3(tb.light(lt, 6), tb.light(lt, 7), tb.light(lt, 8)) * u;
         lightDistance = length(y - x);
         phi = normalized(y - x);
         ndot = dot(normalX, phi);
@@ -795,11 +832,13 @@ __device__ __forceinline__ bool directLight(ShadeCtx& cx, bool active, Rng& g, V
 // !PRIMARY: the part of computeLindirect after its trace has hit (rendering.d:390-391) = computeLrefl at the hit.
 // Block-task T = blockIdx.x reads flat entries [T*P, (T+1)*P) of the hit queue and fills segment T of the
 // output queues.
-template <bool PRIMARY>
+template <bool PRIMARY, bool LDST>
 __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, Wavefront wf,
                                                int numKinds) {
   __shared__ uint32_t sCnt[1 + PT_MAX_KINDS];
   if (threadIdx.x <= PT_MAX_KINDS) sCnt[threadIdx.x] = 0;
+  const ShadeTables<LDST> tb{sc, 0};
+  tb.stage();
   __syncthreads();
   uint32_t T = blockIdx.x;
   uint32_t segCap = wf.capQueue / PT_SEGS;
@@ -829,14 +868,14 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg 
         float4 t4 = wf.thr[laneSlot]; Tp = xyz(t4); depth = f2u(t4.w);
         uint2 r = wf.rng[laneSlot]; g.s0 = r.x; g.s1 = r.y;
       }
-      float4 q0 = sc.nrm[3 * tri], q1 = sc.nrm[3 * tri + 1], q2 = sc.nrm[3 * tri + 2];
+      float4 q0 = tb.nrm(3 * tri), q1 = tb.nrm(3 * tri + 1), q2 = tb.nrm(3 * tri + 2);
       normal = interpNormal(xyz(q0), xyz(q1), xyz(q2), hb.x, hb.y);
-      float4 m = sc.mats[f2u(q0.w)];
+      float4 m = tb.mat(f2u(q0.w));
       color = v3(m.y, m.z, m.w);
       emissive = m.x;
     }
     V3 Tw = Tp * (PT_BRDF * color);
-    bool env = directLight(cx, active, g, hitPos, normal, Tw, direct ? f4(color, emissive) : f4(Tw, 0.0f), laneSlot);
+    bool env = directLight(cx, tb, active, g, hitPos, normal, Tw, direct ? f4(color, emissive) : f4(Tw, 0.0f), laneSlot);
     // emissive * color, rendering.d:477; when the sun / sky entry carries it, the kernel that traces them stores L
     if (PRIMARY && active && !(direct && env)) wf.Lacc[laneSlot] = f4(emissive * color, 1.0f);
     if (cfg.mode == 1) {
@@ -1072,8 +1111,12 @@ void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, 
 void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
                  const Wavefront& wf, bool primary) {
   int numKinds = (cfg.hasLights ? (int)sc.numLightGroups : 0) + (cfg.hasSky ? 1 : 0);
-  if (primary) hipLaunchKernelGGL(k_shade<true>, dim3(PT_SEGS), dim3(PT_SHADE_THREADS), 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
-  else hipLaunchKernelGGL(k_shade<false>, dim3(PT_SEGS), dim3(PT_SHADE_THREADS), 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+  const uint32_t lds = shadeTableBytes(sc);
+  const dim3 grid(PT_SEGS), block(PT_SHADE_THREADS);
+  if (primary && lds) hipLaunchKernelGGL((k_shade<true, true>), grid, block, lds, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+  else if (primary) hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+  else if (lds) hipLaunchKernelGGL((k_shade<false, true>), grid, block, lds, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+  else hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
 }
 
 void launchAccumulate(const LaunchCfg& lc, const ViewMasks& masks, const DevCfg& cfg, const PixMap& pm, float4* acc,
