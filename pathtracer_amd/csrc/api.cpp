@@ -245,15 +245,16 @@ uint32_t numKinds(const PtHandle* h) { return h->dsc.numLightGroups + 1; }
 void ensureWavefront(PtHandle* h) {
   const PtConfig& c = h->cfg;
   // Large batches: every launch ends with a tail in which the last waves finish alone, and a batch is ~10 launches.
-  // Measured on the 1080p teapot frame (ms per 256 spp): 4 M slots 70, 16 M 31.6, 32 M 28.0, 64 M 26.8, 128 M 26.4.
-  // HBM has room: 128 B per slot in mode 0 without light groups (64 M slots = 8.6 GB), ~0.9 KB in mode 1 with
-  // 5 indirect chains (32 M slots = 30 GB; chest1 1080p mode 1, ms per 64 spp: 8 M 28.1, 32 M 17.0, 64 M 15.1).
-  uint64_t want = c.batchSlots ? c.batchSlots : (c.mode == 1 ? (1u << 25) : (1u << 26));
+  // Measured on the 1080p teapot frame (ms per 256 spp): 4 M slots 70, 16 M 31.6, 32 M 28.0, 64 M 25.1, 128 M 24.5,
+  // 256 M 23.7, 512 M 24.0.
+  // HBM has room: 128 B per slot in mode 0 without light groups (256 M slots = 34 GB), ~0.9 KB in mode 1 with
+  // 5 indirect chains (64 M slots = 60 GB; chest1 1080p mode 1, ms per 64 spp: 32 M 15.1, 64 M 13.6).
+  uint64_t want = c.batchSlots ? c.batchSlots : (c.mode == 1 ? (1u << 26) : (1u << 28));
   uint64_t frame = (uint64_t)c.width * c.height;
-  // no point in more slots than 64 samples of the whole frame; a multiple of 64 * PT_SEGS so that every block-task's
+  // no point in more slots than 256 samples of the whole frame; a multiple of 64 * PT_SEGS so that every block-task's
   // share of a full batch is whole waves and fits its output segment
   const uint64_t gran = 64ull * PT_SEGS;
-  want = std::min<uint64_t>(want, frame * 64);
+  want = std::min<uint64_t>(want, frame * 256);
   uint32_t NI = c.mode == 1 ? c.numIndirect : 0;
   uint32_t lanes = 1 + NI;
   if (!c.batchSlots) {       // the default yields to the memory that is actually free (the caller may hold most of it)
@@ -267,7 +268,7 @@ void ensureWavefront(PtHandle* h) {
   }
   uint32_t capSlots = (uint32_t)std::min<uint64_t>(((want + gran - 1) / gran) * gran, 0x40000000ull);
   uint64_t capQueue = (uint64_t)capSlots * std::max(1u, NI);
-  if (capQueue > 0x7FFFFFFFull) fail(PT_E_INVALID, "batchSlots * numIndirect too large");
+  if (capQueue > 0x7FFFFFFFull || (uint64_t)capSlots * lanes > 0xFFFFFFFFull) fail(PT_E_INVALID, "batchSlots * numIndirect too large");
   uint32_t kinds = numKinds(h), rounds = c.mode == 1 ? c.maxDepth + 4 : 2;
   Wavefront& w = h->wf;
   if (w.capSlots == capSlots && w.capQueue == (uint32_t)capQueue && w.lanes == lanes && h->wfKinds == kinds && h->wfRounds == rounds) return;
