@@ -204,15 +204,16 @@ void uploadScene(PtHandle* h) {
   h->st.numTriangles = T; h->st.numNodes = bvh.numNodes; h->st.bvhDepth = bvh.depth;
   h->st.numLightGroups = (uint32_t)lt.numGroups();
   h->maskDirty = true; h->texDirty = true;
+  size_t ldsNeed = ((size_t)2 * bvh.numNodes + (size_t)3 * NT) * 16;
+  DevScene& d = h->dsc;
+  d.ldsBytes = (!(h->cfg.flags & PT_FLAG_NO_LDS_SCENE) && ldsNeed <= 156 * 1024) ? (uint32_t)ldsNeed : 0;
+  h->st.sceneInLds = d.ldsBytes ? 1 : 0;
   if (h->cfg.device < 0) { h->haveScene = true; return; }
   auto up = [&](DevBuf& b, const void* src, size_t bytes) {
     b.alloc(bytes);
     HIPCHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
   };
   HIPCHECK(hipStreamSynchronize(h->stream));
-  size_t ldsNeed = ((size_t)2 * bvh.numNodes + (size_t)3 * NT) * 16;
-  DevScene& d = h->dsc;
-  d.ldsBytes = (!(h->cfg.flags & PT_FLAG_NO_LDS_SCENE) && ldsNeed <= 156 * 1024) ? (uint32_t)ldsNeed : 0;
   if (d.ldsBytes) up(h->dNodes, bvh.nodes.data(), bvh.nodes.size() * 4);
   else {                   // traversal from global memory reads the 16-byte quantised nodes
     std::vector<uint32_t> q((size_t)std::max(1u, bvh.numNodes) * 4, 0u);
@@ -535,7 +536,7 @@ int ptgpu_get_bvh(PtHandle* h, float* nodes8, uint32_t* triOrder) {
   return guarded([&]() {
     if (!h) fail(PT_E_INVALID, "null handle");
     if (!h->haveScene) fail(PT_E_STATE, "no scene");
-    if (nodes8 && h->cfg.device >= 0 && h->dsc.ldsBytes == 0) {       // the boxes the kernels traverse: on the grid
+    if (nodes8 && h->dsc.ldsBytes == 0) {       // the boxes the kernels traverse: on the grid
       std::vector<uint32_t> q((size_t)std::max(1u, h->bvh.numNodes) * 4, 0u);
       float base[3], scale[3];
       quantizeNodes(h->bvh.nodes.data(), h->bvh.numNodes, q.data(), base, scale);

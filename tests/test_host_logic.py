@@ -347,3 +347,23 @@ def test_texcoords_of_uploaded_scenes_default_to_zero_and_can_be_set():
         pt.set_texcoords(tex[:10])
     pt.upload_scene(fl['v'], fl['n'], fl['mat_idx'], fl['materials'])      # a new scene drops them
     assert not pt.get_texcoords().any()
+
+
+@pytest.mark.parametrize('name', NAMES + ['soup'])
+def test_quantised_nodes_contain_their_boxes(name, flats):
+    """Scenes traversed from global memory get 16-byte nodes on a 16-bit grid over the root box: every box returned for
+    such a scene contains the float box of the same node, by no more than a few grid cells, and the tree is the same."""
+    if name == 'soup':
+        fl = soup(3000, seed=11); a = host_tracer(flat=fl); b = host_tracer(flat=fl, flags=P.PT_FLAG_NO_LDS_SCENE)
+    else:
+        a = host_tracer(name); b = host_tracer(name, flags=P.PT_FLAG_NO_LDS_SCENE)
+    assert b.stats().sceneInLds == 0
+    (na, oa), (nb, ob) = a.get_bvh(), b.get_bvh()
+    assert np.array_equal(oa, ob) and np.array_equal(na[:, 3].view(np.uint32), nb[:, 3].view(np.uint32))
+    real = na[:, 4:7] >= na[:, 0:3]                      # padding nodes are empty boxes
+    real = real.all(1)
+    real[1] = False                                       # node 1 only keeps sibling pairs aligned
+    mn_a, mx_a, mn_b, mx_b = na[real, 0:3], na[real, 4:7], nb[real, 0:3], nb[real, 4:7]
+    assert (mn_b <= mn_a).all() and (mx_b >= mx_a).all()
+    cell = (na[0, 4:7] - na[0, 0:3]) / 65529.0
+    assert ((mn_a - mn_b) <= 3.01 * cell + 1e-30).all() and ((mx_b - mx_a) <= 3.01 * cell + 1e-30).all()
