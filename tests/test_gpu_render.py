@@ -15,7 +15,7 @@ import pytest
 
 import oracle_py
 import pathtracer_amd as P
-from conftest import CAMERAS, GOLDEN, make_oracle, make_tracer
+from conftest import CAMERAS, GOLDEN, make_oracle, make_tracer, soup
 
 pytestmark = pytest.mark.gpu
 NAMES = sorted(CAMERAS)
@@ -270,3 +270,32 @@ def test_full_size_properties(require_gpu):
     is_sky = np.all(np.abs(c - sky) < 1e-6, axis=1)
     is_sun = np.all(c > 0.99, axis=1)
     assert (is_sky | is_sun | (c.max(1) > 1)).all() and is_sky.mean() > 0.99
+
+
+@pytest.mark.parametrize('flags', [0, P.PT_FLAG_NO_LDS_SCENE])
+@pytest.mark.parametrize('mode', [0, 1])
+def test_lights_and_sky_together_equal_oracle_with_same_streams(require_gpu, flags, mode):
+    """A scene with a light group AND the sky: the light-sample kernel adds to a vertex's radiance first, the sun/sky
+    kernel then reads, adds and writes it back (it may store it outright only when nothing precedes it).  Same streams
+    as the oracle; directions go through sin/cos, so single visibility decisions may flip (tolerance as for sky scenes)."""
+    fl = soup(1500, seed=21, size=12.0)                   # big triangles: most view rays hit, many shadow rays are blocked
+    W, H = 96, 64
+    cam = P.Camera(30.0, H / W).setTransform((250, 180, 160), (0, 0, 0), (0, 0, 1))
+    pt = P.PathTracer(W, H, has_sky=1, mode=mode, seed=5, flags=flags)
+    pt.upload_scene(fl['v'], fl['n'], fl['mat_idx'], fl['materials']); pt.set_camera(cam)
+    assert pt.stats().numLightGroups >= 1 and pt.stats().sceneInLds == (0 if flags else 1)
+    o = oracle_py.Oracle(fl, build_tree=False); o.configure(width=W, height=H, has_sky=True, mode=mode, seed=5); o.set_camera(cam.state)
+    spp = 8
+    pt.render_frame(spp); got = pt.read_pixels()
+    ref = oracle_py.new_pixels(W * H); _, cn = o.render_keyed(ref, 0, spp, nthreads=8)
+    assert np.array_equal(got['n'], ref['n'])
+    st = pt.stats()
+    assert st.raysLight > 0 and st.raysOcclusion > 0
+    if mode == 0:
+        d = np.abs(got['color'] - ref['color']).max(1)
+        assert (d > 1e-4).mean() < 0.003 and rel_rmse(got['color'], ref['color']) < 3e-3
+        assert int(st.raysLight) == int(cn[0]) - W * H * spp and abs(int(st.raysOcclusion) - int(cn[1])) <= 2e-4 * int(cn[1])
+    else:
+        o.configure(width=W, height=H, has_sky=True, mode=mode, seed=6)
+        other = oracle_py.new_pixels(W * H); o.render_keyed(other, 0, spp, nthreads=8)
+        assert rel_rmse(got['color'], ref['color']) < 0.15 * rel_rmse(other['color'], ref['color'])
