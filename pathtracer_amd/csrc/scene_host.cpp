@@ -206,7 +206,7 @@ bool buildCoverageMask(const FlatScene& scene, const Camera& cam, uint32_t W, ui
     bool finite = true;
     for (int k = 0; k < 9; k++) finite = finite && std::isfinite(p[k]);
     if (!finite) continue;                                    // never hit (no BVH leaf holds it)
-    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300, vx[3], vy[3];
     for (int v = 0; v < 3; v++) {
       double q[3] = {(double)p[3 * v] - cam.pos.x, (double)p[3 * v + 1] - cam.pos.y, (double)p[3 * v + 2] - cam.pos.z};
       double t = inv[0][0] * q[0] + inv[0][1] * q[1] + inv[0][2] * q[2];
@@ -214,6 +214,7 @@ bool buildCoverageMask(const FlatScene& scene, const Camera& cam, uint32_t W, ui
       double b = inv[2][0] * q[0] + inv[2][1] * q[1] + inv[2][2] * q[2];
       if (!(t > tMin)) return false;
       double px = (a / (t * sx) + 1.0) * 0.5 * (double)W, py = (b / (t * sy) + 1.0) * 0.5 * (double)H;   // in pixels
+      vx[v] = px; vy[v] = py;
       x0 = std::min(x0, px); x1 = std::max(x1, px); y0 = std::min(y0, py); y1 = std::max(y1, py);
     }
     double c0 = std::ceil(x0 - margin), c1 = std::floor(x1 + margin), r0 = std::ceil(y0 - margin), r1 = std::floor(y1 + margin);
@@ -221,9 +222,31 @@ bool buildCoverageMask(const FlatScene& scene, const Camera& cam, uint32_t W, ui
     uint32_t ca = (uint32_t)std::max(0.0, c0), cb = (uint32_t)std::min((double)W - 1, c1);
     uint32_t ra = (uint32_t)std::max(0.0, r0), rb = (uint32_t)std::min((double)H - 1, r1);
     if (ca > cb || ra > rb) continue;
-    uint32_t wa = ca >> 5, wb = cb >> 5;
-    uint32_t first = 0xFFFFFFFFu << (ca & 31), last = 0xFFFFFFFFu >> (31 - (cb & 31));
+    // Inside that rectangle, the pixels whose square of sample positions (half size = margin) reaches the projected
+    // triangle: for every edge, the corner of the square farthest to the inner side must not be outside of it.  All
+    // vertices are in front of the camera, so the projection of the triangle is the triangle of the projections.
+    // E_k(x, y) = A_k x + B_k y + C_k >= 0 inside; a sliver (no usable orientation) keeps the whole rectangle.
+    double A[3], B[3], C[3];
+    double area2 = (vx[1] - vx[0]) * (vy[2] - vy[0]) - (vx[2] - vx[0]) * (vy[1] - vy[0]);
+    bool edges = std::fabs(area2) > 1e-9;
+    for (int k = 0; k < 3 && edges; k++) {
+      int k1 = (k + 1) % 3;
+      double sgn = area2 > 0.0 ? 1.0 : -1.0;
+      A[k] = sgn * (vy[k] - vy[k1]); B[k] = sgn * (vx[k1] - vx[k]); C[k] = -(A[k] * vx[k] + B[k] * vy[k]);
+    }
     for (uint32_t r = ra; r <= rb; r++) {
+      double lo = (double)ca, hi = (double)cb;
+      for (int k = 0; k < 3 && edges; k++) {
+        double reach = margin * (std::fabs(A[k]) + std::fabs(B[k]));
+        double kk = B[k] * (double)r + C[k] + reach + 1e-9 * (std::fabs(A[k]) + std::fabs(B[k]) + std::fabs(C[k]) + 1.0);
+        if (A[k] > 0.0) lo = std::max(lo, std::ceil(-kk / A[k] - 1e-9));
+        else if (A[k] < 0.0) hi = std::min(hi, std::floor(-kk / A[k] + 1e-9));
+        else if (kk < 0.0) hi = lo - 1.0;
+      }
+      if (!(lo <= hi)) continue;
+      uint32_t a = (uint32_t)lo, b = (uint32_t)hi;
+      uint32_t wa = a >> 5, wb = b >> 5;
+      uint32_t first = 0xFFFFFFFFu << (a & 31), last = 0xFFFFFFFFu >> (31 - (b & 31));
       uint32_t* row = &rows[(size_t)r * wordsPerRow];
       if (wa == wb) row[wa] |= first & last;
       else { row[wa] |= first; for (uint32_t w = wa + 1; w < wb; w++) row[w] = 0xFFFFFFFFu; row[wb] |= last; }

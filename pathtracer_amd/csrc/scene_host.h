@@ -46,8 +46,8 @@ void findLights(const FlatScene& scene, LightTable& out);
 Camera cameraLookAt(float fovDegrees, float aspect, V3 from, V3 to, V3 up);
 
 // Conservative coverage mask of the view rays (getViewRay, rendering.d:278-285): bit p of `bits` is set when some
-// triangle's screen-space bounding rectangle, grown by the half-pixel jitter of the sample positions plus a margin,
-// overlaps pixel p.  A view ray of a pixel whose bit is clear cannot hit anything.  Bit p of `constantSky` is set when
+// triangle's projection reaches the square of pixel p's sample positions (half a pixel of jitter each way plus a
+// margin; tested edge by edge inside the projection's bounding rectangle).  A view ray of a pixel whose bit is clear cannot hit anything.  Bit p of `constantSky` is set when
 // in addition no sample position of the pixel sees sampleSky's sun disc (rendering.d:332-339): every sample of that
 // pixel is the sky constant.  Returns false (outputs unspecified) when the masks cannot be built: a triangle is not
 // strictly in front of the camera, or the camera basis is singular.
