@@ -4,14 +4,15 @@
 // whole batch of paths; the stages talk through structure-of-arrays queues in HBM:
 //
 //   raygen             getViewRay (rendering.d:278-285) + the part of Scene.trace that can be decided per pixel
-//                      (coverage mask of the triangles' screen rectangles, else the scene's bounding box): rays
+//                      (coverage mask of the triangles' projections, else the scene's bounding box): rays
 //                      that cannot hit take the `else` branch of computeL right away (sampleSky, rendering.d:480);
 //                      the rest are compacted into a ray queue
 //   extend             Scene.trace (scene.d:681-743) of a ray queue: view rays, later the indirect rays
 //   shade              computeL / computeLdirect / computeLindirect bodies between the trace calls
 //                                                           rendering.d:376-462, 472-481
 //   connect            Scene.trace of a light-sample ray + the G term   rendering.d:414-425
-//   occluded           Scene.hitsNothing of the sun / sky rays          rendering.d:440-443, 455-457
+//   occluded           Scene.hitsNothing of the sun and sky rays (one queue entry per vertex carries both)
+//                                                           rendering.d:440-443, 455-457
 //   accumulate         sum += L; n += 1                                  rendering.d:477-483
 //
 // Live paths are compacted when they are appended to the next queue.  Queues are segmented (kernels.h, QMeta):
@@ -23,7 +24,8 @@
 // dynamically, 64 entries per wave at a time (WorkPool), because traversal times vary by an order of magnitude.
 //
 // Traversal: stack-based, near child first, over the BVH2 of bvh.h.  When the scene fits, nodes and
-// triangles are staged in LDS once per (persistent) workgroup; otherwise they are read from HBM/L2.
+// triangles are staged in LDS once per (persistent) workgroup; otherwise they are read from HBM/L2, the nodes
+// in a 16-byte form with the box planes on a 16-bit grid (bvh.h: quantizeNodes).
 // The ray-box test is conservative (boxes are padded at build time, far distance inflated by 2 ulp) and
 // the ray-triangle test is evaluated in one fixed order with explicit fma (pt_math.h), so the closest
 // hit (t, u, v, triangle id) does not depend on the tree.
