@@ -235,7 +235,7 @@ def cpu_baseline(wl, W, H, model, target_seconds):
     orc.set_camera(oracle_py.camera_lookat(30.0, H / W, wl['frm'], wl['to'], (0, 0, 1)))
     px = oracle_py.new_pixels(W * H)
     sec1, cn1 = orc.render_mt(px, 1, nthreads=cores, use_tree=True)
-    passes = int(max(1, min(32, target_seconds / max(sec1, 1e-3))))
+    passes = int(max(1, min(wl["spp"], target_seconds / max(sec1, 1e-3))))
     sec, cn = orc.render_mt(px, passes, nthreads=cores, use_tree=True)
     rays = float(cn[0] + cn[1])
     return {'value': round(rays / sec / 1e6, 3), 'unit': 'Mrays/s', 'cores': cores, 'kind': 'port',
