@@ -325,11 +325,17 @@ __device__ __forceinline__ Task taskOf(const QMeta& q, uint32_t T) {
   Task t; t.begin = T * P; t.end = min(t.begin + P, total); t.seg = q.start[T];
   return t;
 }
-// Physical index of flat entry j; seg is the lane's cursor (j only grows within a block-task).
-__device__ __forceinline__ uint32_t physIndex(const QMeta& q, uint32_t j, uint32_t& seg, uint32_t segCap) {
-  uint32_t lo = q.prefix[seg], hi = q.prefix[seg + 1];
-  while (j >= hi) { seg++; lo = hi; hi = q.prefix[seg + 1]; }
-  return seg * segCap + (j - lo);
+// Physical index of flat entry j through the lane's cursor (j only grows within a block-task).  The cursor keeps
+// the bounds of its segment in registers: the prefix array is read again only when j leaves the segment, not once
+// per entry (a read per entry puts one more memory round trip in front of every iteration of shade).
+struct SegCursor { uint32_t seg, lo, hi; };
+__device__ __forceinline__ SegCursor segCursor(const QMeta& q, uint32_t seg) {
+  SegCursor c; c.seg = seg; c.lo = q.prefix[seg]; c.hi = q.prefix[seg + 1];
+  return c;
+}
+__device__ __forceinline__ uint32_t physIndex(const QMeta& q, uint32_t j, SegCursor& c, uint32_t segCap) {
+  while (j >= c.hi) { c.seg++; c.lo = c.hi; c.hi = q.prefix[c.seg + 1]; }
+  return c.seg * segCap + (j - c.lo);
 }
 __device__ __forceinline__ uint32_t dense64(uint32_t total) { return ((total + PT_SEGS - 1) / PT_SEGS + 63u) & ~63u; }
 
@@ -847,7 +853,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg 
   ShadeCtx cx{sc, cfg, wf, sCnt, T, segCap, segCap};
   const bool direct = envDirect(cfg, sc, PRIMARY);
   Task tk = taskOf(wf.hitQ, T);
-  uint32_t seg = tk.seg;
+  SegCursor seg = segCursor(wf.hitQ, tk.seg);
   for (uint32_t base = tk.begin; base < tk.end; base += blockDim.x) {
     uint32_t j = base + threadIdx.x;
     bool active = j < tk.end;
