@@ -369,13 +369,18 @@ __global__ void __launch_bounds__(1024) k_scan(const QMeta* __restrict__ metas, 
   q.start[tid] = s;
 }
 
-// Physical index of flat entry j, starting the search at any segment (a hint that may be off in either direction).
-__device__ __forceinline__ uint32_t physIndexHint(const QMeta& q, uint32_t j, uint32_t seg, uint32_t segCap) {
-  uint32_t lo = q.prefix[seg];
-  while (j < lo) { seg--; lo = q.prefix[seg]; }
-  uint32_t hi = q.prefix[seg + 1];
-  while (j >= hi) { seg++; lo = hi; hi = q.prefix[seg + 1]; }
-  return seg * segCap + (j - lo);
+// Physical index of flat entry j for the traversal kernels' lanes.  The lane keeps the bounds of the segment its
+// last entry was in (consecutive chunks of a wave come from the same 2048 entries, i.e. nearly always the same
+// segment) and searches again, from the hint `seg` (which may be off in either direction), only when j is outside.
+__device__ __forceinline__ uint32_t physIndexHint(const QMeta& q, uint32_t j, uint32_t seg, uint32_t segCap, SegCursor& c) {
+  if (j < c.lo || j >= c.hi) {
+    uint32_t lo = q.prefix[seg];
+    while (j < lo) { seg--; lo = q.prefix[seg]; }
+    uint32_t hi = q.prefix[seg + 1];
+    while (j >= hi) { seg++; lo = hi; hi = q.prefix[seg + 1]; }
+    c.seg = seg; c.lo = lo; c.hi = hi;
+  }
+  return c.seg * segCap + (j - c.lo);
 }
 
 // Dynamic distribution of a flat queue over the waves of the persistent traversal kernels.  The launch's global
@@ -550,13 +555,14 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend(DevScene sc, DevCfg cfg, PixMap pm,
   const uint32_t segLast = (uint32_t)(((uint64_t)(blockIdx.x + 1) * PT_SEGS) / gridDim.x);
   const uint32_t outBase = segFirst * segCapOut, outLimit = (segLast - segFirst) * segCapOut;
   if (!PRIMARY && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&wf.stats[STAT_RAYS_INDIRECT], (unsigned long long)total);
+  SegCursor cur; cur.seg = 0; cur.lo = 1; cur.hi = 0;      // empty: the first entry searches
   Chunk ck;
   while (nextChunk(&pool, wf.taskCounters, q, total, outLimit, ck)) {
     uint32_t j = ck.begin + (threadIdx.x & 63u);
     bool isHit = false;
     V3 hitPos = v3(0, 0, 0); Hit h; h.t = 0; h.u = 0; h.v = 0; h.tri = 0; uint32_t slot = 0;
     if (j < ck.end) {
-      uint32_t e = physIndexHint(q, j, ck.seg, segCapIn);
+      uint32_t e = physIndexHint(q, j, ck.seg, segCapIn, cur);
       V3 o, d;
       if (PRIMARY) {
         float4 sd = wf.slotQ[e];
@@ -651,11 +657,12 @@ __global__ void PT_TRAVERSAL_BOUNDS k_connect(DevScene sc, float eps, QMeta q, u
   uint32_t cN = 0, cT = 0;
   const uint32_t total = q.prefix[PT_SEGS];
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[STAT_RAYS_LIGHT], (unsigned long long)total);
+  SegCursor cur; cur.seg = 0; cur.lo = 1; cur.hi = 0;      // empty: the first entry searches
   Chunk ck;
   while (nextChunk(&pool, taskCounter, q, total, 0, ck)) {
     uint32_t j = ck.begin + (threadIdx.x & 63u);
     if (j < ck.end) {
-      uint32_t e = physIndexHint(q, j, ck.seg, segCap);
+      uint32_t e = physIndexHint(q, j, ck.seg, segCap, cur);
       float4 ro = shO[e], rd = shD[e];
       V3 phi = xyz(rd);
       Hit h;
@@ -697,11 +704,12 @@ __global__ void PT_TRAVERSAL_BOUNDS k_occluded(DevScene sc, float eps, V3 sunRad
   __syncthreads();
   uint32_t cN = 0, cT = 0, nRays = 0;
   const uint32_t total = q.prefix[PT_SEGS];
+  SegCursor cur; cur.seg = 0; cur.lo = 1; cur.hi = 0;      // empty: the first entry searches
   Chunk ck;
   while (nextChunk(&pool, taskCounter, q, total, 0, ck)) {
     uint32_t j = ck.begin + (threadIdx.x & 63u);
     if (j < ck.end) {
-      uint32_t e = physIndexHint(q, j, ck.seg, segCap);
+      uint32_t e = physIndexHint(q, j, ck.seg, segCap, cur);
       float4 ro = shO[e], a = shD[e], b = shW[e];
       bool eSun = a.x != 0.0f || a.y != 0.0f || a.z != 0.0f, eSky = b.x != 0.0f || b.y != 0.0f || b.z != 0.0f;
       nRays += (eSun ? 1u : 0u) + (eSky ? 1u : 0u);
