@@ -292,3 +292,22 @@ def test_visit_counters_match_cpu_restatement_of_the_traversal(require_gpu, flat
         n_nodes, n_tris, tri = o.bvh_count(nodes, root, order, rays, any_hit=order_rule)
         assert np.array_equal(free, tri < 0)
         assert abs(st.nodesAny - n_nodes) <= 1e-3 * n_nodes and abs(st.trisAny - n_tris) <= 1e-3 * n_tris
+
+
+@pytest.mark.parametrize('extent,size,offset', [(1e4, 1e-2, 0.0), (5.0, 3.0, 1e5), (1e-3, 4e-4, 0.0), (100.0, 40.0, -3e3)])
+def test_quantised_nodes_on_extreme_scales(require_gpu, extent, size, offset):
+    """Scenes traversed from global memory (16-bit box grid over the root box) whose scale defeats naive rounding:
+    triangles far smaller than a grid cell, coordinates far from the origin (the grid-to-world map is evaluated in
+    fp32), a scene of millimetre extent, triangles as large as the scene.  Hits must equal the exhaustive oracle's."""
+    fl = soup(2500, seed=3, extent=extent, size=size)
+    fl['v'] = (fl['v'] + np.float32(offset)).astype(np.float32)
+    pt = P.PathTracer(16, 16, flags=P.PT_FLAG_NO_LDS_SCENE, eps=1e-5 if extent > 1 else 1e-12)
+    pt.upload_scene(fl['v'], fl['n'], fl['mat_idx'], fl['materials'])
+    assert pt.stats().sceneInLds == 0
+    o = oracle_py.Oracle(fl, build_tree=False); o.configure(width=16, height=16, eps=1e-5 if extent > 1 else 1e-12)
+    rays = random_rays(fl, 12000, 17)
+    tri, t, u, v, _ = pt.trace(rays)
+    ref = o.trace_rays(rays, kind=0, use_tree=False)
+    assert_hits_equal((tri, t, u, v), ref)
+    assert np.array_equal(pt.hitsNothing(rays), o.trace_rays(rays, kind=1, use_tree=False)[0] < 0)
+    assert (ref[0] >= 0).sum() > 50
