@@ -53,7 +53,8 @@ typedef struct PtConfig {
   uint32_t seed;             /* RNG key; streams are keyed (seed, pixel, sample, stream)              */
   uint32_t sampleBase;       /* added to a pixel's sample index: sample-slice split across GPUs       */
   uint32_t batchSlots;       /* path slots per wavefront batch, 0 = default                           */
-  uint32_t maxLeafTris;      /* BVH leaf size bound (1..15), 0 = default                              */
+  uint32_t maxLeafTris;      /* BVH leaf size bound (1..15); 0 = the library chooses: 4, or up to 8     */
+                             /* when fuller leaves let one more workgroup per CU keep the scene in LDS */
   uint32_t flags;            /* PT_FLAG_*                                                             */
 } PtConfig;
 

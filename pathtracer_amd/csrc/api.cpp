@@ -87,7 +87,6 @@ void normalizeConfig(PtConfig& c) {
   if (c.rrProb == 0.0f) c.rrProb = 0.7f;
   if (c.maxDepth == 0) c.maxDepth = 5;
   if (c.numIndirect == 0) c.numIndirect = 5;
-  if (c.maxLeafTris == 0) c.maxLeafTris = 4;
   if (c.maxLeafTris > BVH_MAX_LEAF) c.maxLeafTris = BVH_MAX_LEAF;
 }
 
@@ -159,16 +158,37 @@ void uploadScene(PtHandle* h) {
   // The binned-SAH build on one host core takes ~1 s per million triangles; from 1 M triangles up the tree is built
   // on the GPU instead (Morton-order LBVH: more traversal steps per ray, but the soup builds in a fraction of a second).
   const uint32_t f = h->cfg.flags;
+  const bool autoLeaf = h->cfg.maxLeafTris == 0;          // 0: the library chooses (4, more when that fits the scene in LDS)
+  const uint32_t leafCap = autoLeaf ? 4u : h->cfg.maxLeafTris;
   bool onGpu = false;
   if (h->cfg.device >= 0 && !(f & PT_FLAG_HOST_BVH) && ((f & PT_FLAG_GPU_BVH) || T >= 1000000u)) {
     std::string why;
     // leaves of at most 2 triangles: the collapse of the radix tree is blind to surface areas, and with 4 the soup's
     // rays test 5x as many triangles as in the SAH tree (measured, 10 M triangles: build 0.28 s vs 9.1 s on the host,
     // 698 vs 735 Mrays/s; leaves of 4: 675, of 1: 672)
-    onGpu = buildBvhGpu(fs.v.data(), T, std::min(h->cfg.maxLeafTris, 2u), h->bvh, why);
+    onGpu = buildBvhGpu(fs.v.data(), T, std::min(leafCap, 2u), h->bvh, why);
     h->bvhNote = onGpu ? "" : why;
   }
-  if (!onGpu) buildBvh(fs.v.data(), T, h->cfg.maxLeafTris, h->bvh);
+  if (!onGpu) {
+    buildBvh(fs.v.data(), T, leafCap, h->bvh);
+    // Tree shape for LDS residency: the traversal kernels keep a copy of nodes + triangles per workgroup, and how many
+    // workgroups share a CU steps down at 18 / 38 / 78 / 156 KB.  A scene just above a step is rebuilt with fuller
+    // leaves (fewer nodes) when that gets it under the step: twice the waves per CU outweigh the extra triangle tests
+    // (1300 big triangles: 130.9 KB -> 76.4 KB, 18.9 -> 15.0 ms per 64 spp at 1080p; 2400: 237 KB, traversed from
+    // global memory, -> 147.5 KB in LDS, 35.0 -> 31.7 ms).  With an explicit maxLeafTris only the cost changes.
+    auto footprint = [](const Bvh& b) { return ((uint64_t)2 * b.numNodes + (uint64_t)3 * b.triOrder.size()) * 16; };
+    if (!(f & PT_FLAG_NO_LDS_SCENE) && (uint64_t)T * 48 <= 156 * 1024) {
+      uint32_t best = ldsWorkgroupsPerCU(footprint(h->bvh));
+      const uint32_t leaves[3] = {leafCap, autoLeaf ? std::max(leafCap, 6u) : leafCap, autoLeaf ? std::max(leafCap, 8u) : leafCap};
+      for (int k = 0; k < 3 && best < 8; k++) {
+        if (k > 0 && leaves[k] == leaves[k - 1]) continue;
+        if (ldsWorkgroupsPerCU((uint64_t)T * 48) <= best) break;          // the triangles alone do not fit the next step
+        Bvh alt; buildBvh(fs.v.data(), T, leaves[k], alt, 0.25f);
+        uint32_t cls = ldsWorkgroupsPerCU(footprint(alt));
+        if (cls > best) { alt.buildSeconds += h->bvh.buildSeconds; h->bvh = std::move(alt); best = cls; }
+      }
+    }
+  }
   h->st.bvhOnGpu = onGpu ? 1u : 0u; h->st.bvhBuildSeconds = h->bvh.buildSeconds;
   const Bvh& bvh = h->bvh;
 

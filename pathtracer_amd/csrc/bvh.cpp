@@ -23,12 +23,12 @@ struct Box {
 struct Work { uint32_t node, first, count, depth; };
 
 constexpr int NBINS = 16;
-constexpr float COST_TRI = 1.0f;     // one triangle test
 constexpr float COST_PAIR = 1.0f;    // one step that fetches and tests a sibling pair
 
 }  // namespace
 
-void buildBvh(const float* v, uint32_t T, uint32_t maxLeaf, Bvh& out) {
+void buildBvh(const float* v, uint32_t T, uint32_t maxLeaf, Bvh& out, float triCost) {
+  const float COST_TRI = triCost;
   auto t0 = std::chrono::steady_clock::now();
   out = Bvh();
   maxLeaf = std::max(1u, std::min(maxLeaf, BVH_MAX_LEAF));

@@ -32,7 +32,8 @@ void quantizeNodes(const float* nodes, uint32_t numNodes, uint32_t* out, float q
 // The boxes the quantised tree stands for, in the layout of Bvh::nodes.
 void dequantizeNodes(const uint32_t* q, uint32_t numNodes, const float qBase[3], const float qScale[3], float* nodes);
 
-// v = T x 9 floats (v0, v1, v2).  Binned-SAH top-down build, leaves of at most maxLeaf triangles.
-void buildBvh(const float* v, uint32_t T, uint32_t maxLeaf, Bvh& out);
+// v = T x 9 floats (v0, v1, v2).  Binned-SAH top-down build, leaves of at most maxLeaf triangles.  triCost: cost of a
+// triangle test relative to a step (one sibling pair): below 1 the tree gets fewer nodes and fuller leaves.
+void buildBvh(const float* v, uint32_t T, uint32_t maxLeaf, Bvh& out, float triCost = 1.0f);
 
 }  // namespace pt

@@ -149,6 +149,11 @@ struct Wavefront {
 enum { STAT_RAYS_LIGHT = 0, STAT_RAYS_INDIRECT, STAT_RAYS_OCCL, STAT_NODES_CLOSEST, STAT_TRIS_CLOSEST,
        STAT_NODES_ANY, STAT_TRIS_ANY, STAT_RAYS_CULLED, STAT_COUNT };
 
+// Workgroups of a traversal kernel per CU when the scene copy in LDS takes `bytes` (0: it does not fit at all).
+inline uint32_t ldsWorkgroupsPerCU(uint64_t bytes) {
+  return bytes <= 18 * 1024 ? 8u : bytes <= 38 * 1024 ? 4u : bytes <= 78 * 1024 ? 2u : bytes <= 156 * 1024 ? 1u : 0u;
+}
+
 // Shading tables (vertex normals, materials, light triangles, light groups) small enough for every shade workgroup
 // to keep a copy in LDS: bytes of that copy, or 0 when they are read from global memory.
 inline uint32_t shadeTableBytes(const DevScene& sc) {

@@ -1047,10 +1047,7 @@ Geo traversalGeo(const LaunchCfg& lc, const DevScene& sc, uint64_t maxItems) {
   Geo g; g.lds = sc.ldsBytes;
   uint32_t bs, perCU;
   if (sc.ldsBytes == 0) { bs = 512; perCU = 4; }
-  else if (sc.ldsBytes <= 18 * 1024) { bs = 256; perCU = 8; }
-  else if (sc.ldsBytes <= 38 * 1024) { bs = 512; perCU = 4; }
-  else if (sc.ldsBytes <= 78 * 1024) { bs = 1024; perCU = 2; }
-  else { bs = 1024; perCU = 1; }
+  else { perCU = std::max(1u, ldsWorkgroupsPerCU(sc.ldsBytes)); bs = perCU == 8 ? 256 : perCU == 4 ? 512 : 1024; }
   uint64_t want = (maxItems + bs - 1) / bs;
   uint64_t cap = (uint64_t)lc.numCUs * perCU;
   g.block = dim3(bs); g.grid = dim3((unsigned)std::max<uint64_t>(1, std::min(want, cap)));
