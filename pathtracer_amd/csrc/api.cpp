@@ -171,20 +171,22 @@ void uploadScene(PtHandle* h) {
   }
   if (!onGpu) {
     buildBvh(fs.v.data(), T, leafCap, h->bvh);
-    // Tree shape for LDS residency: the traversal kernels keep a copy of nodes + triangles per workgroup, and how many
-    // workgroups share a CU steps down at 18 / 38 / 78 / 156 KB.  A scene just above a step is rebuilt with fuller
-    // leaves (fewer nodes) when that gets it under the step: twice the waves per CU outweigh the extra triangle tests
+    // Tree shape for LDS residency: the traversal kernels keep a copy of nodes + triangles per workgroup.  Up to 78 KB
+    // a CU holds 32 waves of them (8 x 256, 4 x 512 or 2 x 1024 threads), up to 156 KB one workgroup of 16 waves,
+    // beyond that the scene is traversed from global memory.  A scene just above one of these two steps is rebuilt
+    // with fuller leaves (fewer nodes) when that gets it under the step: the waves outweigh the extra triangle tests
     // (1300 big triangles: 130.9 KB -> 76.4 KB, 18.9 -> 15.0 ms per 64 spp at 1080p; 2400: 237 KB, traversed from
     // global memory, -> 147.5 KB in LDS, 35.0 -> 31.7 ms).  With an explicit maxLeafTris only the cost changes.
     auto footprint = [](const Bvh& b) { return ((uint64_t)2 * b.numNodes + (uint64_t)3 * b.triOrder.size()) * 16; };
     if (!(f & PT_FLAG_NO_LDS_SCENE) && (uint64_t)T * 48 <= 156 * 1024) {
-      uint32_t best = ldsWorkgroupsPerCU(footprint(h->bvh));
+      auto residency = [](uint64_t bytes) { return bytes <= 78 * 1024 ? 2u : bytes <= 156 * 1024 ? 1u : 0u; };
+      uint32_t best = residency(footprint(h->bvh));
       const uint32_t leaves[3] = {leafCap, autoLeaf ? std::max(leafCap, 6u) : leafCap, autoLeaf ? std::max(leafCap, 8u) : leafCap};
-      for (int k = 0; k < 3 && best < 8; k++) {
+      for (int k = 0; k < 3 && best < 2; k++) {
         if (k > 0 && leaves[k] == leaves[k - 1]) continue;
-        if (ldsWorkgroupsPerCU((uint64_t)T * 48) <= best) break;          // the triangles alone do not fit the next step
+        if (residency((uint64_t)T * 48) <= best) break;                    // the triangles alone do not fit the next step
         Bvh alt; buildBvh(fs.v.data(), T, leaves[k], alt, 0.25f);
-        uint32_t cls = ldsWorkgroupsPerCU(footprint(alt));
+        uint32_t cls = residency(footprint(alt));
         if (cls > best) { alt.buildSeconds += h->bvh.buildSeconds; h->bvh = std::move(alt); best = cls; }
       }
     }
