@@ -51,7 +51,10 @@ typedef struct PtConfig {
   uint32_t maxDepth;         /* depth cap of computeLindirect, 5 if 0                                 */
   uint32_t numIndirect;      /* N of computeL, 5 if 0                                                 */
   uint32_t seed;             /* RNG key; streams are keyed (seed, pixel, sample, stream)              */
-  uint32_t sampleBase;       /* added to a pixel's sample index: sample-slice split across GPUs       */
+  uint32_t sampleBase;       /* sample k of a pixel (k = Pixel.n so far + position in the call) draws the streams   */
+  uint32_t sampleStride;     /* of index sampleBase + k * sampleStride (stride 1 if 0).  G GPUs that each render   */
+                             /* every pixel use base = rank, stride = G: their index sets stay disjoint over any   */
+                             /* number of passes and across checkpoint / resume                                     */
   uint32_t batchSlots;       /* path slots per wavefront batch, 0 = default                           */
   uint32_t maxLeafTris;      /* BVH leaf size bound (1..15); 0 = the library chooses: 4, or up to 8     */
                              /* when fuller leaves let one more workgroup per CU keep the scene in LDS */
@@ -169,6 +172,10 @@ int ptgpu_trace_primary(PtHandle* h, uint32_t pixelOffset, uint32_t count, int32
 int ptgpu_view_rays(PtHandle* h, uint32_t pixelOffset, uint32_t count, float* rays6);
 /* First n words of RNG stream (seed, pixel, sample, stream) as the kernels draw them. */
 int ptgpu_rng_stream(PtHandle* h, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n, uint32_t* out);
+/* Parity probe: angleToDirection(phi, psi, normal) (rendering.d:316-330) as the shading kernels evaluate it, for n rows
+ * of 5 floats (phi, psi, normal.xyz); a row with a zero normal gets angleToLocalDirection(phi, psi) (rendering.d:309-314).
+ * out3 = n x 3.  cosf / sinf are evaluated in binary64 in one fixed order and rounded once (pt_math.h: sincosFixed). */
+int ptgpu_angle_directions(PtHandle* h, const float* in5, uint32_t n, float* out3);
 /* Parity probe (no reference counterpart): the masks the view rays of getViewRay (rendering.d:278-285) are culled
  * with for the current scene and camera, ceil(width*height/32) words each, either may be NULL.  Bit p of covered is
  * set when pixel p may see a triangle; bit p of constantSky when it cannot and in addition none of its sample

@@ -44,6 +44,8 @@
 //   S10 uniform(a,b) = a + (b-a)*r, r = (x>>8)*2^-24 in [0,1)
 //   S11 Triangle.area = 0.5*|(v1-v0)x(v2-v0)|
 //   S12 A in B (spheres) <=> |cA-cB| + rA <= rB ; Sphere.radius = sqrtf(radiusSquared)
+//   S13 cosf / sinf: one fixed binary64 evaluation rounded once (sincosS13), within 1 ulp of libm
+//   S14 powf(x, 1/2.4) of the tone map: one fixed binary64 evaluation rounded once (powInv24S14)
 // Everything else is evaluated left to right as the D source writes it, one IEEE float
 // operation per operator, no contraction (compile with -ffp-contract=off).
 // =====================================================================================
@@ -456,13 +458,35 @@ V3 pickRandomLightPoint(const Scene& sc, Rng& gen, uint32_t li) {   // rendering
   }
 }
 
+// cosf / sinf of the reference (rendering.d:309-330), S13: evaluated in binary64 in one fixed order and rounded to
+// binary32 once -- k = rint(x * 2/pi), r = x - k*pi/2 in two pieces, Taylor sin (through r^11) and cos (through
+// r^12) by Horner with fma, quadrant from k -- so that every implementation of this sequence returns the same bits.
+// Within 1 ulp of libm (test_oracle.py); the product evaluates the same sequence (pt_math.h: sincosFixed).
+void sincosS13(float x, float& sn, float& cs) {
+  double xd = (double)x;
+  double k = std::rint(xd * 0.63661977236758134308);
+  double r = std::fma(-k, 1.57079632679489655800, xd);
+  r = std::fma(-k, 6.12323399573676603587e-17, r);
+  double r2 = r * r;
+  static const double SC[5] = {-1.0 / 39916800.0, 1.0 / 362880.0, -1.0 / 5040.0, 1.0 / 120.0, -1.0 / 6.0};
+  static const double CC[6] = {1.0 / 479001600.0, -1.0 / 3628800.0, 1.0 / 40320.0, -1.0 / 720.0, 1.0 / 24.0, -0.5};
+  double ps = SC[0]; for (int i = 1; i < 5; i++) ps = std::fma(ps, r2, SC[i]);
+  double pc = CC[0]; for (int i = 1; i < 6; i++) pc = std::fma(pc, r2, CC[i]);
+  double s = std::fma(r * r2, ps, r), c = std::fma(r2, pc, 1.0);
+  switch ((int)(long long)k & 3) {
+    case 0: sn = (float)s; cs = (float)c; break;
+    case 1: sn = (float)c; cs = (float)(-s); break;
+    case 2: sn = (float)(-s); cs = (float)(-c); break;
+    default: sn = (float)(-c); cs = (float)s; break;
+  }
+}
 V3 angleToLocalDirection(float phi, float psi) {                    // rendering.d:309-314
-  float cosPhi = cosf(phi);
-  return v3(cosf(psi) * cosPhi, sinf(psi) * cosPhi, sinf(phi));
+  float sinPhi, cosPhi, sinPsi, cosPsi;
+  sincosS13(phi, sinPhi, cosPhi); sincosS13(psi, sinPsi, cosPsi);
+  return v3(cosPsi * cosPhi, sinPsi * cosPhi, sinPhi);
 }
 V3 angleToDirection(float phi, float psi, V3 normal) {              // rendering.d:316-330
-  float cosPhi = cosf(phi);
-  V3 localDir = v3(cosf(psi) * cosPhi, sinf(psi) * cosPhi, sinf(phi));
+  V3 localDir = angleToLocalDirection(phi, psi);
   V3 up = normal, dir = v3(1, 0, 0);
   if (fabsf(dot(dir, up)) > 0.9f) dir = v3(0, 1, 0);
   V3 right = normalized(cross(up, dir));
@@ -755,9 +779,9 @@ double orc_render_mt(void* h, Pixel* pixels, uint32_t spp, uint32_t nthreads, in
 }
 
 // Same estimator with counter-keyed RNG streams (seed, pixel, sample, stream): sample index of a
-// pixel = sampleBase + (uint)pixel.n.  Independent of threads and of how pixels are partitioned.
+// pixel = sampleBase + (uint)pixel.n * sampleStride.  Independent of threads and of how pixels are partitioned.
 double orc_render_keyed(void* h, uint32_t pixelOffset, uint32_t count, Pixel* pixels, uint32_t spp, uint32_t sampleBase,
-                        uint32_t nthreads, int useTree, uint64_t* counters) {
+                        uint32_t sampleStride, uint32_t nthreads, int useTree, uint64_t* counters) {
   Scene* s = (Scene*)h;
   if (nthreads < 1) nthreads = 1;
   std::vector<Counters> cns(nthreads);
@@ -771,7 +795,7 @@ double orc_render_keyed(void* h, uint32_t pixelOffset, uint32_t count, Pixel* pi
       uint32_t e = std::min(count, b + chunk);
       for (uint32_t i = b; i < e; i++)
         for (uint32_t k = 0; k < spp; k++)
-          computeL(tr, pixelOffset + i, pixels[i], gen, true, sampleBase + (uint32_t)pixels[i].n);
+          computeL(tr, pixelOffset + i, pixels[i], gen, true, sampleBase + (uint32_t)pixels[i].n * sampleStride);
     }
     cns[tid] = tr.cn;
   };
@@ -791,16 +815,57 @@ void orc_keyed_stream(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t s
   for (uint32_t i = 0; i < n; i++) out[i] = g.next();
 }
 
-// drawScreen's scalar path, main.d:82-95: saturate -> sRGB OETF -> cast(ubyte)(x*255) (truncation)
+// pow(c, 1/2.4) of drawScreen (main.d:92), S14: binary64, one fixed order, rounded to binary32 once.  c = m * 2^e
+// with m in [sqrt(1/2), sqrt(2)); ln m = 2 f (1 + f^2/3 + ... + f^12/13), f = (m-1)/(m+1); y = (e ln2 + ln m) / 2.4
+// (as a product with the double 1/2.4); n = rint(y / ln2); exp(y - n ln2) by Taylor through the 11th power; * 2^n.
+// Within 1 ulp of libm's powf (test_oracle.py); the product evaluates the same sequence (pt_math.h: powInv24Fixed).
+float powInv24S14(float c) {
+  double xd = (double)c;
+  uint64_t bits; std::memcpy(&bits, &xd, 8);
+  int e = (int)((bits >> 52) & 0x7FFu) - 1023;
+  bits = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+  double m; std::memcpy(&m, &bits, 8);
+  if (m > 1.41421356237309514547) { m = m * 0.5; e = e + 1; }
+  double f = (m - 1.0) / (m + 1.0), f2 = f * f;
+  static const double LC[7] = {1.0 / 13.0, 1.0 / 11.0, 1.0 / 9.0, 1.0 / 7.0, 1.0 / 5.0, 1.0 / 3.0, 1.0};
+  double pl = LC[0]; for (int i = 1; i < 7; i++) pl = std::fma(pl, f2, LC[i]);
+  double lnm = 2.0 * f * pl;
+  double lnx = std::fma((double)e, 0.69314718055994528623, lnm);
+  double y = lnx * (1.0 / 2.4);
+  double n = std::rint(y * 1.44269504088896338700);
+  double g = std::fma(-n, 0.69314718055994528623, y);
+  static const double EC[12] = {1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0,
+                                1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0, 1.0};
+  double pe = EC[0]; for (int i = 1; i < 12; i++) pe = std::fma(pe, g, EC[i]);
+  uint64_t sb = (uint64_t)((int64_t)n + 1023) << 52;
+  double scale; std::memcpy(&scale, &sb, 8);
+  return (float)(pe * scale);
+}
+
+// drawScreen's scalar path, main.d:82-95: saturate -> sRGB OETF -> cast(ubyte)(x*255) (truncation).  A NaN channel
+// (the cast is undefined for it) is written as 0.
 void orc_tonemap(const Pixel* pixels, uint32_t count, uint8_t* rgb) {
-  const float a = 0.055f, aPlusOne = 1 + 0.055f, power = 1 / 2.4f;
+  const float a = 0.055f, aPlusOne = 1 + 0.055f;
   for (uint32_t i = 0; i < count; i++)
     for (int k = 0; k < 3; k++) {
       float c = pixels[i].color[k];
+      if (!(c == c)) { rgb[3 * i + k] = 0; continue; }
       c = c < 0.0f ? 0.0f : (c > 1.0f ? 1.0f : c);
-      c = (c <= 0.0031308f) ? c * 12.92f : aPlusOne * powf(c, power) - a;
+      c = (c <= 0.0031308f) ? c * 12.92f : aPlusOne * powInv24S14(c) - a;
       rgb[3 * i + k] = (uint8_t)(c * 255.0f);
     }
+}
+// Probes of S13 / S14 and of the direction helpers, for cross-checks against libm and against the device.
+void orc_sincos(const float* x, uint32_t n, float* s, float* c) { for (uint32_t i = 0; i < n; i++) sincosS13(x[i], s[i], c[i]); }
+void orc_pow_inv24(const float* x, uint32_t n, float* y) { for (uint32_t i = 0; i < n; i++) y[i] = powInv24S14(x[i]); }
+// angleToDirection(phi, psi, normal) (rendering.d:316-330); a zero normal selects angleToLocalDirection (:309-314).
+// in = n x (phi, psi, nx, ny, nz), out = n x 3
+void orc_angle_directions(const float* in5, uint32_t n, float* out3) {
+  for (uint32_t i = 0; i < n; i++) {
+    const float* p = in5 + 5 * i; V3 nn = v3(p[2], p[3], p[4]);
+    V3 d = (nn.x == 0.0f && nn.y == 0.0f && nn.z == 0.0f) ? angleToLocalDirection(p[0], p[1]) : angleToDirection(p[0], p[1], nn);
+    out3[3 * i] = d.x; out3[3 * i + 1] = d.y; out3[3 * i + 2] = d.z;
+  }
 }
 
 // Traversal-cost model for the roofline: walks the PRODUCT's flattened BVH (nodes8 = {min.xyz, ref, max.xyz, 0},

@@ -52,8 +52,11 @@ def lib():
         L.orc_render_mt.restype = C.c_double
         L.orc_render_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_render_keyed.restype = C.c_double
-        L.orc_render_keyed.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
+        L.orc_render_keyed.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_uint32, C.c_int, C.c_void_p]
+        L.orc_sincos.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_pow_inv24.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_angle_directions.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_keyed_stream.argtypes = [C.c_uint32] * 5 + [C.c_void_p]
         L.orc_tonemap.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_bvh_count.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
@@ -176,9 +179,10 @@ class Oracle:
         sec = lib().orc_render_mt(self.h, _p(pixels), spp, nthreads, int(use_tree), _p(cn))
         return sec, cn
 
-    def render_keyed(self, pixels, offset, spp, sample_base=0, nthreads=1, use_tree=False):
+    def render_keyed(self, pixels, offset, spp, sample_base=0, nthreads=1, use_tree=False, sample_stride=1):
         cn = np.zeros(4, np.uint64)
-        sec = lib().orc_render_keyed(self.h, offset, len(pixels), _p(pixels), spp, sample_base, nthreads, int(use_tree), _p(cn))
+        sec = lib().orc_render_keyed(self.h, offset, len(pixels), _p(pixels), spp, sample_base, sample_stride, nthreads,
+                                     int(use_tree), _p(cn))
         return sec, cn
 
 
@@ -194,6 +198,28 @@ def default_sky_radiance():
 def keyed_stream(seed, pixel, sample, stream, n):
     out = np.empty(n, np.uint32)
     lib().orc_keyed_stream(seed, pixel, sample, stream, n, _p(out))
+    return out
+
+
+def sincos(x):
+    """S13: the oracle's fixed evaluation of sinf / cosf."""
+    x = np.ascontiguousarray(x, np.float32); s = np.empty_like(x); c = np.empty_like(x)
+    lib().orc_sincos(_p(x), len(x), _p(s), _p(c))
+    return s, c
+
+
+def pow_inv24(x):
+    """S14: the oracle's fixed evaluation of powf(x, 1 / 2.4)."""
+    x = np.ascontiguousarray(x, np.float32); y = np.empty_like(x)
+    lib().orc_pow_inv24(_p(x), len(x), _p(y))
+    return y
+
+
+def angle_directions(phi, psi, normals):
+    """angleToDirection (rendering.d:316-330); rows with a zero normal use angleToLocalDirection (:309-314)."""
+    a = np.ascontiguousarray(np.column_stack([phi, psi, normals]), np.float32)
+    out = np.empty((len(a), 3), np.float32)
+    lib().orc_angle_directions(_p(a), len(a), _p(out))
     return out
 
 

@@ -17,7 +17,7 @@ class PtConfig(C.Structure):
                 ('hasSky', C.c_uint32), ('hasLights', C.c_uint32), ('sunDir', C.c_float * 3),
                 ('sunRadiance', C.c_float * 3), ('skyRadiance', C.c_float * 3), ('floatEpsilon', C.c_float),
                 ('rrProb', C.c_float), ('maxDepth', C.c_uint32), ('numIndirect', C.c_uint32), ('seed', C.c_uint32),
-                ('sampleBase', C.c_uint32), ('batchSlots', C.c_uint32), ('maxLeafTris', C.c_uint32),
+                ('sampleBase', C.c_uint32), ('sampleStride', C.c_uint32), ('batchSlots', C.c_uint32), ('maxLeafTris', C.c_uint32),
                 ('flags', C.c_uint32)]
 
 
@@ -60,6 +60,7 @@ SYMBOLS = {
     'ptgpu_trace_primary': (_I, [_VP, _U32, _U32, _VP, _VP, _VP, _VP]),
     'ptgpu_view_rays': (_I, [_VP, _U32, _U32, _VP]),
     'ptgpu_rng_stream': (_I, [_VP, _U32, _U32, _U32, _U32, _VP]),
+    'ptgpu_angle_directions': (_I, [_VP, _VP, _U32, _VP]),
     'ptgpu_get_coverage_mask': (_I, [_VP, _VP, _VP, _VP]),
     'ptgpu_get_stats': (_I, [_VP, C.POINTER(PtStats)]),
     'ptgpu_reset_stats': (_I, [_VP]),

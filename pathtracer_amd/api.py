@@ -84,7 +84,7 @@ class PathTracer:
             raise PtError(rc, self.lib.ptgpu_last_error().decode(errors='replace'))
 
     _ALIASES = {'has_sky': 'hasSky', 'has_lights': 'hasLights', 'eps': 'floatEpsilon', 'rr': 'rrProb',
-                'max_depth': 'maxDepth', 'n_indirect': 'numIndirect', 'sample_base': 'sampleBase',
+                'max_depth': 'maxDepth', 'n_indirect': 'numIndirect', 'sample_base': 'sampleBase', 'sample_stride': 'sampleStride',
                 'batch_slots': 'batchSlots', 'max_leaf_tris': 'maxLeafTris', 'sun_dir': 'sunDir',
                 'sun_radiance': 'sunRadiance', 'sky_radiance': 'skyRadiance'}
 
@@ -255,6 +255,14 @@ class PathTracer:
     def rng_stream(self, pixel, sample, stream, n):
         out = np.zeros(n, np.uint32)
         self._check(self.lib.ptgpu_rng_stream(self.h, pixel, sample, stream, n, _ptr(out)))
+        return out
+
+    def angle_directions(self, phi, psi, normals):
+        """angleToDirection(phi, psi, normal) (rendering.d:316-330) on the device; zero normal rows:
+        angleToLocalDirection (rendering.d:309-314)."""
+        a = np.ascontiguousarray(np.column_stack([phi, psi, normals]), np.float32)
+        out = np.zeros((len(a), 3), np.float32)
+        self._check(self.lib.ptgpu_angle_directions(self.h, _ptr(a), len(a), _ptr(out)))
         return out
 
     def coverage_mask(self, constant_sky=False):

@@ -87,6 +87,7 @@ void normalizeConfig(PtConfig& c) {
   if (c.rrProb == 0.0f) c.rrProb = 0.7f;
   if (c.maxDepth == 0) c.maxDepth = 5;
   if (c.numIndirect == 0) c.numIndirect = 5;
+  if (c.sampleStride == 0) c.sampleStride = 1;
   if (c.maxLeafTris > BVH_MAX_LEAF) c.maxLeafTris = BVH_MAX_LEAF;
 }
 
@@ -105,7 +106,7 @@ DevCfg makeDevCfg(const PtHandle* h) {
   d.sunRadiance = v3(c.sunRadiance[0], c.sunRadiance[1], c.sunRadiance[2]);
   d.skyRadiance = v3(c.skyRadiance[0], c.skyRadiance[1], c.skyRadiance[2]);
   d.eps = c.floatEpsilon; d.rrProb = c.rrProb; d.maxDepth = c.maxDepth; d.numIndirect = c.numIndirect;
-  d.seed = c.seed; d.sampleBase = c.sampleBase; d.cam = h->cam;
+  d.seed = c.seed; d.sampleBase = c.sampleBase; d.sampleStride = c.sampleStride; d.cam = h->cam;
   d.divW = makeFastDiv(c.width);
   return d;
 }
@@ -376,7 +377,7 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm) 
   h->st.raysPrimary += nslots; h->st.samples += nslots;
   if (dc.mode == 1)      // depth 0..maxDepth can still spawn a ray (the check is depth > maxDepth, rendering.d:380)
     for (uint32_t round = 0; round <= dc.maxDepth; round++) stage(round + 2, false);
-  { Timed t(h, PT_K_ACCUM); launchAccumulate(lc, h->masks(), dc, pm, h->acc, wf); t.done(); }
+  { Timed t(h, PT_K_ACCUM); launchAccumulate(lc, h->masks(), dc, pm, h->acc, wf, h->dsc); t.done(); }
   HIPCHECK(hipGetLastError());
 }
 
@@ -817,6 +818,20 @@ int ptgpu_rng_stream(PtHandle* h, uint32_t pixel, uint32_t sample, uint32_t stre
     DevBuf d; d.alloc((size_t)n * 4);
     launchRngStream(makeLaunchCfg(h), h->cfg.seed, pixel, sample, stream, n, d.as<uint32_t>());
     HIPCHECK(hipMemcpyAsync(out, d.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+  });
+}
+
+int ptgpu_angle_directions(PtHandle* h, const float* in5, uint32_t n, float* out3) {
+  return guarded([&]() {
+    if (!h || ((!in5 || !out3) && n)) fail(PT_E_INVALID, "null argument");
+    useDevice(h);
+    if (!n) return;
+    DevBuf di, dout; di.alloc((size_t)n * 20); dout.alloc((size_t)n * 12);
+    HIPCHECK(hipMemcpyAsync(di.p, in5, (size_t)n * 20, hipMemcpyHostToDevice, h->stream));
+    launchAngleDirections(makeLaunchCfg(h), di.as<float>(), n, dout.as<float>());
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(out3, dout.p, (size_t)n * 12, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
   });
 }

@@ -59,7 +59,7 @@ struct DevCfg {               // PtConfig + camera as the kernels need them
   uint32_t W, H, mode, hasSky, hasLights;
   V3 sunDir, sunRadiance, skyRadiance;
   float eps, rrProb;
-  uint32_t maxDepth, numIndirect, seed, sampleBase;
+  uint32_t maxDepth, numIndirect, seed, sampleBase, sampleStride;
   Camera cam;
   FastDiv divW;
 };
@@ -126,7 +126,8 @@ struct Wavefront {
   float4* rayD;               //                     (dir.xyz, 0)
   float4* hitA;               // hit queue (filled by extend, hits only): (hit position.xyz, triangle id)
   float4* hitB;               //                                          (u, v, lane slot, t)
-  float4* Lacc;               // per lane slot: radiance gathered by this lane (xyz), primary-hit flag (w)
+  float4* Lacc;               // per lane slot: radiance gathered by this lane (xyz); w of a view-ray slot: bits of
+                              // (material index + 1) when the view ray hit, 0 when it missed
   float4* thr;                // per lane slot: throughput of the chain (xyz), depth (w)
   uint2* rng;                 // per lane slot: generator state
   float4* shO;                // shadow queues, kind-major: (origin.xyz, lane slot)
@@ -184,7 +185,7 @@ void launchConnect(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, c
 // primary: the queue was filled by the shading of view-ray hits
 void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, bool primary);
 void launchAccumulate(const LaunchCfg& lc, const ViewMasks& masks, const DevCfg& cfg, const PixMap& pm, float4* acc,
-                      const Wavefront& wf);
+                      const Wavefront& wf, const DevScene& sc);
 
 // ---- stand-alone operators ----
 void launchExtendPrimary(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
@@ -197,6 +198,7 @@ void launchTraceTex(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, 
 void launchHitsNothing(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const float* rays6, uint32_t count,
                        uint8_t* out, unsigned long long* stats);
 void launchTonemap(const LaunchCfg& lc, const float4* acc, uint32_t pixelOffset, uint32_t count, uint8_t* rgb);
+void launchAngleDirections(const LaunchCfg& lc, const float* in5, uint32_t n, float* out3);
 void launchRngStream(const LaunchCfg& lc, uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n,
                      uint32_t* out);
 

@@ -451,7 +451,7 @@ __device__ __forceinline__ PrimaryRay primaryRayFrom(const DevCfg& cfg, uint32_t
   uint32_t row = fdiv(cfg.divW, r.gp), col = r.gp - row * cfg.W;
   float x, y;
   if (jitter) {
-    r.sampleIdx = cfg.sampleBase + (uint32_t)accW + s;
+    r.sampleIdx = cfg.sampleBase + ((uint32_t)accW + s) * cfg.sampleStride;
     r.g.seed(cfg.seed, r.gp, r.sampleIdx, 0);
     viewRayXY(col, row, cfg.W, cfg.H, &r.g, x, y);
   } else {
@@ -690,9 +690,9 @@ __global__ void PT_TRAVERSAL_BOUNDS k_connect(DevScene sc, float eps, QMeta q, u
 
 // Sun and sky rays of one vertex: Scene.hitsNothing + `L += ...`, rendering.d:440-443 and 455-457.  An entry is
 // (origin, lane slot), (sun direction, n.sunDir), (sky direction, n.dir) and X; a zero direction is not traced.
-// direct: the vertex is a view-ray hit whose L nothing else adds to before this kernel; X = (color, emissive) and the
-// kernel stores L = emissive * color + ... (rendering.d:477) without reading it.  Otherwise X = (BRDF * color scaled
-// by the chain's throughput, -) and L is read, added to and written back when a ray got through.
+// direct: the vertex is a view-ray hit whose L nothing else adds to before this kernel; X = (color, material tag) and
+// the kernel stores L = 0 + ... with the tag (see k_accumulate) without reading it.  Otherwise X = (BRDF * color
+// scaled by the chain's throughput, -) and L is read, added to and written back when a ray got through.
 template <bool LDSS, bool COUNT>
 __global__ void PT_TRAVERSAL_BOUNDS k_occluded(DevScene sc, float eps, V3 sunRadiance, V3 skyRadiance, int direct, QMeta q,
                                                    uint32_t segCap, const float4* __restrict__ shO, const float4* __restrict__ shD,
@@ -724,7 +724,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_occluded(DevScene sc, float eps, V3 sunRad
         float4 x = shX[e];
         uint32_t slot = f2u(ro.w);
         V3 Tw; float4 L;
-        if (direct) { V3 color = xyz(x); Tw = v3(1, 1, 1) * (PT_BRDF * color); L = f4(x.w * color, 1.0f); }
+        if (direct) { V3 color = xyz(x); Tw = v3(1, 1, 1) * (PT_BRDF * color); L = make_float4(0.0f, 0.0f, 0.0f, x.w); }
         else { Tw = xyz(x); L = Lacc[slot]; }
         if (vSun) { V3 c = Tw * sunRadiance * a.w; L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; }
         if (vSky) { V3 c = Tw * skyRadiance * b.w; L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; }
@@ -867,7 +867,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg 
     bool active = j < tk.end;
     V3 Tp = v3(1, 1, 1), hitPos = v3(0, 0, 0), normal = v3(0, 0, 1), color = v3(0, 0, 0);
     uint32_t laneSlot = 0, depth = 0, gp = 0, sampleIdx = 0;
-    float emissive = 0.0f;
+    uint32_t matTag = 0;                     // material index + 1: marks the slot as a view-ray hit (k_accumulate)
     Rng g; g.s0 = 1; g.s1 = 0;
     if (active) {
       uint32_t e = physIndex(wf.hitQ, j, seg, wf.capHit / PT_SEGS);
@@ -877,7 +877,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg 
       if (PRIMARY) {
         uint32_t s = fdiv(pm.divNpix, laneSlot), lp = laneSlot - s * pm.npix;
         gp = mapPixel(pm, cfg.W, lp);
-        sampleIdx = cfg.sampleBase + (uint32_t)acc[gp].w + s;
+        sampleIdx = cfg.sampleBase + ((uint32_t)acc[gp].w + s) * cfg.sampleStride;
         g.seed(cfg.seed, gp, sampleIdx, 0);
         g.next(); g.next();                                            // the x and y jitter of getViewRay
       } else {
@@ -888,12 +888,13 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg 
       normal = interpNormal(xyz(q0), xyz(q1), xyz(q2), hb.x, hb.y);
       float4 m = tb.mat(f2u(q0.w));
       color = v3(m.y, m.z, m.w);
-      emissive = m.x;
+      matTag = f2u(q0.w) + 1u;
     }
     V3 Tw = Tp * (PT_BRDF * color);
-    bool env = directLight(cx, tb, active, g, hitPos, normal, Tw, direct ? f4(color, emissive) : f4(Tw, 0.0f), laneSlot);
-    // emissive * color, rendering.d:477; when the sun / sky entry carries it, the kernel that traces them stores L
-    if (PRIMARY && active && !(direct && env)) wf.Lacc[laneSlot] = f4(emissive * color, 1.0f);
+    bool env = directLight(cx, tb, active, g, hitPos, normal, Tw, direct ? f4(color, u2f(matTag)) : f4(Tw, 0.0f), laneSlot);
+    // `vec3 L;` of computeLdirect (rendering.d:399) + the tag; when the sun / sky entry carries it, the kernel that
+    // traces them stores L
+    if (PRIMARY && active && !(direct && env)) wf.Lacc[laneSlot] = make_float4(0.0f, 0.0f, 0.0f, u2f(matTag));
     if (cfg.mode == 1) {
       if (PRIMARY) {
         for (uint32_t c = 0; c < cfg.numIndirect; c++) {               // the loop at rendering.d:474-476
@@ -915,7 +916,11 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg 
 // ------------------------------------------------------------------------------------------------ accumulate
 // pixel.sum += L; pixel.n += 1 for each of the batch's k samples of a pixel, in sample order
 // (rendering.d:477-482; the (sum / N) of the indirect chains as in the block at rendering.d:474-477).
-__global__ void __launch_bounds__(256) k_accumulate(ViewMasks masks, DevCfg cfg, PixMap pm, float4* __restrict__ acc, Wavefront wf) {
+// A slot's radiance record is (L, tag): for a view-ray hit L is computeLdirect's sum, gathered from 0 in the
+// reference's order (light groups, sun, sky), and tag = material index + 1, so that emissive * color is added in
+// front of it as the source does (`emissive * color + computeLdirect(...)`); for a miss L = sampleSky and tag = 0.
+__global__ void __launch_bounds__(256) k_accumulate(ViewMasks masks, DevCfg cfg, PixMap pm, float4* __restrict__ acc, Wavefront wf,
+                                                    const float4* __restrict__ mats) {
   uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
   if (lp >= pm.npix) return;
   uint32_t gp = mapPixel(pm, cfg.W, lp);
@@ -931,10 +936,15 @@ __global__ void __launch_bounds__(256) k_accumulate(ViewMasks masks, DevCfg cfg,
     uint32_t slot = s * pm.npix + lp;
     float4 L = wf.Lacc[slot];
     V3 add = xyz(L);
-    if (cfg.mode == 1 && L.w != 0.0f) {
-      V3 sum = v3(0, 0, 0);
-      for (uint32_t c = 0; c < cfg.numIndirect; c++) sum = sum + xyz(wf.Lacc[(size_t)(c + 1) * wf.capSlots + slot]);
-      add = add + sum / (float)cfg.numIndirect;
+    const uint32_t tag = f2u(L.w);
+    if (tag) {
+      float4 m = mats[tag - 1u];
+      add = m.x * v3(m.y, m.z, m.w) + add;
+      if (cfg.mode == 1) {
+        V3 sum = v3(0, 0, 0);
+        for (uint32_t c = 0; c < cfg.numIndirect; c++) sum = sum + xyz(wf.Lacc[(size_t)(c + 1) * wf.capSlots + slot]);
+        add = add + sum / (float)cfg.numIndirect;
+      }
     }
     a.x += add.x; a.y += add.y; a.z += add.z; a.w += 1.0f;
   }
@@ -1021,14 +1031,19 @@ __global__ void k_tonemap(const float4* __restrict__ acc, uint32_t pixelOffset, 
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   float4 a = acc[pixelOffset + i];
-  const float A = 0.055f, aPlusOne = 1 + 0.055f, power = 1 / 2.4f;
-  float c[3] = {a.x / a.w, a.y / a.w, a.z / a.w};
-  for (int k = 0; k < 3; k++) {
-    float x = a.w > 0.0f ? c[k] : 0.0f;
-    x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
-    x = (x <= 0.0031308f) ? x * 12.92f : aPlusOne * powf(x, power) - A;
-    rgb[3 * (size_t)i + k] = (uint8_t)(x * 255.0f);
-  }
+  float c[3] = {a.x / a.w, a.y / a.w, a.z / a.w};                     // pixel.color = pixel.sum / pixel.n
+  for (int k = 0; k < 3; k++) rgb[3 * (size_t)i + k] = tonemapChannel(a.w > 0.0f ? c[k] : 0.0f);
+}
+
+// angleToDirection (rendering.d:316-330) as the shading kernels evaluate it; a zero normal selects
+// angleToLocalDirection (rendering.d:309-314).  in5 = (phi, psi, normal) per row.
+__global__ void k_angle_directions(const float* __restrict__ in5, uint32_t n, float* __restrict__ out3) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = in5 + 5 * (size_t)i;
+  V3 nn = v3(p[2], p[3], p[4]);
+  V3 d = (nn.x == 0.0f && nn.y == 0.0f && nn.z == 0.0f) ? angleToLocalDirection(p[0], p[1]) : angleToDirection(p[0], p[1], nn);
+  out3[3 * (size_t)i] = d.x; out3[3 * (size_t)i + 1] = d.y; out3[3 * (size_t)i + 2] = d.z;
 }
 
 __global__ void k_rng_stream(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n, uint32_t* out) {
@@ -1133,8 +1148,8 @@ void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, con
 }
 
 void launchAccumulate(const LaunchCfg& lc, const ViewMasks& masks, const DevCfg& cfg, const PixMap& pm, float4* acc,
-                      const Wavefront& wf) {
-  hipLaunchKernelGGL(k_accumulate, dim3((pm.npix + 255) / 256), dim3(256), 0, lc.stream, masks, cfg, pm, acc, wf);
+                      const Wavefront& wf, const DevScene& sc) {
+  hipLaunchKernelGGL(k_accumulate, dim3((pm.npix + 255) / 256), dim3(256), 0, lc.stream, masks, cfg, pm, acc, wf, sc.mats);
 }
 
 void launchViewRays(const LaunchCfg& lc, const DevCfg& cfg, uint32_t pixelOffset, uint32_t count, float* rays6) {
@@ -1174,6 +1189,10 @@ void launchHitsNothing(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cf
 
 void launchTonemap(const LaunchCfg& lc, const float4* acc, uint32_t pixelOffset, uint32_t count, uint8_t* rgb) {
   hipLaunchKernelGGL(k_tonemap, dim3((count + 255) / 256), dim3(256), 0, lc.stream, acc, pixelOffset, count, rgb);
+}
+
+void launchAngleDirections(const LaunchCfg& lc, const float* in5, uint32_t n, float* out3) {
+  hipLaunchKernelGGL(k_angle_directions, dim3((n + 255) / 256), dim3(256), 0, lc.stream, in5, n, out3);
 }
 
 void launchRngStream(const LaunchCfg& lc, uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n, uint32_t* out) {

@@ -122,10 +122,94 @@ PT_HD float interpolateComponent(float u, float v, float val0, float val1, float
   return val0 * i2 + interpolated1 * i1;
 }
 
+// ------------------------------------------------------------------ sin, cos, pow with one fixed evaluation
+// cosf / sinf (rendering.d:309-330) and powf (main.d:92) are library calls in the reference; two libraries differ
+// in the last bit, and one bit of a direction can flip a visibility decision.  These evaluate in binary64 with an
+// explicit sequence of fma / * / + / rint / IEEE division, rounded to binary32 once, so that host and device (and
+// any restatement that uses the same constants and order) return the same bits.  Error before the final rounding
+// < 1e-11 (sin, cos, |x| <= 1e4) and < 1e-13 relative (pow): the result is the correctly rounded one except in about
+// one case in 10^4, where it is its neighbour.
+//
+// sin and cos of x: k = rint(x * 2/pi); r = x - k * pi/2 (pi/2 = HI + LO); Taylor polynomials in r on [-pi/4, pi/4]
+// (sin through r^11, cos through r^12), Horner with fma from the highest coefficient; quadrant k & 3.
+PT_HD void sincosFixed(float x, float* sinOut, float* cosOut) {
+  const double xd = (double)x;
+  const double k = rint(xd * 0.63661977236758134308);                // 2 / pi
+  double r = fma(-k, 1.57079632679489655800, xd);                    // pi / 2, leading 53 bits
+  r = fma(-k, 6.12323399573676603587e-17, r);                        // pi / 2, next 53 bits
+  const double r2 = r * r;
+  double ps = -1.0 / 39916800.0;                                     // -1/11!
+  ps = fma(ps, r2, 1.0 / 362880.0);                                  //  1/9!
+  ps = fma(ps, r2, -1.0 / 5040.0);                                   // -1/7!
+  ps = fma(ps, r2, 1.0 / 120.0);                                     //  1/5!
+  ps = fma(ps, r2, -1.0 / 6.0);                                      // -1/3!
+  const double s = fma(r * r2, ps, r);
+  double pc = 1.0 / 479001600.0;                                     //  1/12!
+  pc = fma(pc, r2, -1.0 / 3628800.0);                                // -1/10!
+  pc = fma(pc, r2, 1.0 / 40320.0);                                   //  1/8!
+  pc = fma(pc, r2, -1.0 / 720.0);                                    // -1/6!
+  pc = fma(pc, r2, 1.0 / 24.0);                                      //  1/4!
+  pc = fma(pc, r2, -0.5);                                            // -1/2!
+  const double c = fma(r2, pc, 1.0);
+  const int q = (int)(long long)k & 3;
+  const double sq = (q & 1) ? c : s, cq = (q & 1) ? s : c;
+  *sinOut = (float)((q & 2) ? -sq : sq);
+  *cosOut = (float)(((q + 1) & 2) ? -cq : cq);
+}
+
+// x^(1/2.4) for x in (0, 1] (the sRGB curve of drawScreen, main.d:92): x = m * 2^e with m in [sqrt(1/2), sqrt(2));
+// ln m = 2 atanh(f), f = (m - 1) / (m + 1), series through f^13; y = (e ln 2 + ln m) * (1 / 2.4); n = rint(y / ln 2);
+// g = y - n ln 2; exp(g) by Taylor through g^11; result scaled by 2^n.
+PT_HD float powInv24Fixed(float x) {
+  const double xd = (double)x;
+  unsigned long long bits; __builtin_memcpy(&bits, &xd, 8);
+  int e = (int)((bits >> 52) & 0x7FFu) - 1023;
+  bits = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;     // mantissa in [1, 2)
+  double m; __builtin_memcpy(&m, &bits, 8);
+  if (m > 1.41421356237309514547) { m = m * 0.5; e = e + 1; }
+  const double f = (m - 1.0) / (m + 1.0), f2 = f * f;
+  double pl = 1.0 / 13.0;
+  pl = fma(pl, f2, 1.0 / 11.0);
+  pl = fma(pl, f2, 1.0 / 9.0);
+  pl = fma(pl, f2, 1.0 / 7.0);
+  pl = fma(pl, f2, 1.0 / 5.0);
+  pl = fma(pl, f2, 1.0 / 3.0);
+  pl = fma(pl, f2, 1.0);
+  const double lnm = 2.0 * f * pl;
+  const double lnx = fma((double)e, 0.69314718055994528623, lnm);
+  const double y = lnx * (1.0 / 2.4);
+  const double n = rint(y * 1.44269504088896338700);                 // 1 / ln 2
+  const double g = fma(-n, 0.69314718055994528623, y);               // |g| <= 0.35
+  double pe = 1.0 / 39916800.0;                                      // 1/11!
+  pe = fma(pe, g, 1.0 / 3628800.0);
+  pe = fma(pe, g, 1.0 / 362880.0);
+  pe = fma(pe, g, 1.0 / 40320.0);
+  pe = fma(pe, g, 1.0 / 5040.0);
+  pe = fma(pe, g, 1.0 / 720.0);
+  pe = fma(pe, g, 1.0 / 120.0);
+  pe = fma(pe, g, 1.0 / 24.0);
+  pe = fma(pe, g, 1.0 / 6.0);
+  pe = fma(pe, g, 0.5);
+  pe = fma(pe, g, 1.0);
+  pe = fma(pe, g, 1.0);
+  unsigned long long sb = (unsigned long long)((long long)n + 1023) << 52;   // 2^n, n in [-1100/2.4, 0]
+  double scale; __builtin_memcpy(&scale, &sb, 8);
+  return (float)(pe * scale);
+}
+
+// drawScreen's scalar path for one channel (main.d:87-93): saturate, sRGB curve, cast(ubyte)(x * 255)
+PT_HD uint8_t tonemapChannel(float x) {
+  const float A = 0.055f, aPlusOne = 1 + 0.055f;
+  if (!(x == x)) return 0;                                           // NaN (the cast is undefined for it)
+  x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+  x = (x <= 0.0031308f) ? x * 12.92f : aPlusOne * powInv24Fixed(x) - A;
+  return (uint8_t)(x * 255.0f);
+}
+
 // rendering.d:309-314
 PT_HD V3 angleToLocalDirection(float phi, float psi) {
-  float sinPhi, cosPhi, sinPsi, cosPsi;                      // one argument reduction per angle instead of two
-  sincosf(phi, &sinPhi, &cosPhi); sincosf(psi, &sinPsi, &cosPsi);
+  float sinPhi, cosPhi, sinPsi, cosPsi;
+  sincosFixed(phi, &sinPhi, &cosPhi); sincosFixed(psi, &sinPsi, &cosPsi);
   return v3(cosPsi * cosPhi, sinPsi * cosPhi, sinPhi);
 }
 // rendering.d:316-330

@@ -58,12 +58,27 @@ void flattenModel(const ModelData& model, int materialTable, const float* modelM
   if (modelMatrix) std::memcpy(mm, modelMatrix, sizeof(mm));
   else if (!mat4Inverse(root.transform, mm)) throw IoError("root node transform is singular");
 
-  std::vector<uint32_t> leafs;                                          // findLeafs, scene.d:213-225
-  std::function<void(uint32_t)> findLeafs = [&](uint32_t i) {
-    if (!model.nodes[i].meshes.empty()) leafs.push_back(i);
-    for (uint32_t c : model.nodes[i].children) findLeafs(c);
-  };
-  findLeafs(0);
+  // findLeafs, scene.d:213-225: depth first from node 0, children in file order.  The reference recurses and trusts
+  // the file; a node reached twice (a cycle, or a node with two parents) would send it into unbounded recursion or
+  // duplicate geometry, so such a file is refused.
+  std::vector<uint32_t> leafs;
+  {
+    std::vector<uint8_t> seen(model.nodes.size(), 0);
+    std::vector<std::pair<uint32_t, size_t>> stack;                     // (node, next child position)
+    stack.push_back({0u, 0});
+    seen[0] = 1;
+    if (!model.nodes[0].meshes.empty()) leafs.push_back(0);
+    while (!stack.empty()) {
+      auto& top = stack.back();
+      const NodeDrawData& nd = model.nodes[top.first];
+      if (top.second == nd.children.size()) { stack.pop_back(); continue; }
+      uint32_t c = nd.children[top.second++];
+      if (seen[c]) throw IoError("thModel: node " + std::to_string(c) + " is reached twice (the node graph is not a tree)");
+      seen[c] = 1;
+      if (!model.nodes[c].meshes.empty()) leafs.push_back(c);
+      stack.push_back({c, 0});
+    }
+  }
   if (leafs.empty()) throw IoError("no leaf nodes found");              // scene.d:226
 
   for (const MaterialData& md : model.materials) {                      // scene.d:239-245
@@ -74,7 +89,9 @@ void flattenModel(const ModelData& model, int materialTable, const float* modelM
     float tr[16];
     mat4Mul(root.transform, mm, tr);                                    // scene.d:257
     int32_t cur = (int32_t)leaf;
+    size_t steps = 0;
     while (cur >= 0 && cur != 0) {                                      // scene.d:258-262
+      if (++steps > model.nodes.size()) throw IoError("thModel: parent links of node " + std::to_string(leaf) + " form a cycle");
       mat4Mul(model.nodes[cur].transform, tr, tr);
       cur = model.nodes[cur].parent;
     }

@@ -11,7 +11,10 @@ namespace {
 
 struct Cursor {
   const uint8_t* d; size_t p, end; std::string name;
-  void need(size_t n) const { if (p + n > end) throw IoError("thModel: unexpected end of chunk '" + name + "'"); }
+  void need(size_t n) const { if (n > end - p) throw IoError("thModel: unexpected end of chunk '" + name + "'"); }
+  // A count read from the file is only believed when the chunk still holds that many records of at least minBytes
+  // each: nothing is allocated for a count the payload cannot back.
+  uint32_t count(size_t minBytes) { uint32_t n = u32(); need((size_t)n * minBytes); return n; }
   uint8_t u8() { need(1); return d[p++]; }
   uint32_t u32() { need(4); uint32_t v; std::memcpy(&v, d + p, 4); p += 4; return v; }
   void raw(void* dst, size_t n) { need(n); std::memcpy(dst, d + p, n); p += n; }
@@ -64,16 +67,16 @@ void LoadFile(const std::string& path, ModelData& out) {
   }
   {  // textures (modelloader.d:338-374)
     Cursor t = file.chunk("textures");
-    uint32_t n = t.u32(); out.textures.resize(n);
+    uint32_t n = t.count(4); out.textures.resize(n);
     for (auto& s : out.textures) { uint32_t len = t.u32(); s = t.str(len); }
   }
   {  // materials (modelloader.d:377-445)
     Cursor m = file.chunk("materials");
-    uint32_t n = m.u32(); out.materials.resize(n);
+    uint32_t n = m.count(8); out.materials.resize(n);                       // an empty "mat" chunk is 8 bytes
     for (auto& mat : out.materials) {
       Cursor c = m.chunk("mat");
       if (out.version >= 2) { uint32_t len = c.u32(); mat.name = c.str(len); }
-      uint32_t nt = c.u32(); mat.textures.resize(nt);
+      uint32_t nt = c.count(5); mat.textures.resize(nt);
       for (auto& tr : mat.textures) {
         tr.textureIndex = c.u32(); tr.semantic = c.u8();
         if (tr.textureIndex >= out.textures.size()) throw IoError("thModel: texture index out of range");
@@ -82,18 +85,20 @@ void LoadFile(const std::string& path, ModelData& out) {
   }
   {  // meshes (modelloader.d:448-633)
     Cursor ms = file.chunk("meshes");
-    uint32_t n = ms.u32(); out.meshes.resize(n);
+    uint32_t n = ms.count(9); out.meshes.resize(n);                         // an empty "mesh" chunk is 9 bytes
     for (auto& mesh : out.meshes) {
       Cursor c = ms.chunk("mesh");
       mesh.materialIndex = c.u32();
       c.raw(mesh.bboxMin, 12); c.raw(mesh.bboxMax, 12);
       uint32_t nv = c.u32();
       Cursor v = c.chunk("vertices");
+      v.need((size_t)nv * 12);
       mesh.vertices.resize((size_t)nv * 3); v.raw(mesh.vertices.data(), (size_t)nv * 12);
       bool faces = false;
       while (!faces) {
         Cursor sub = c.chunk();
         if (sub.name == "normals" || sub.name == "tangents" || sub.name == "bitangents") {
+          sub.need((size_t)nv * 6);
           std::vector<int16_t> q((size_t)nv * 3); sub.raw(q.data(), q.size() * 2);
           if (sub.name == "normals") {
             mesh.normals.resize(q.size());
@@ -104,11 +109,12 @@ void LoadFile(const std::string& path, ModelData& out) {
           for (uint8_t i = 0; i < nsets; i++) {
             uint8_t comps = sub.u8();
             if (comps != 2) throw IoError("Currently only 2 component texture coordinates are supported got " + std::to_string(comps));
+            sub.need((size_t)nv * 8);
             std::vector<float> tc((size_t)nv * 2); sub.raw(tc.data(), tc.size() * 4);
             if (i < 4) mesh.texcoords[i].swap(tc);
           }
         } else if (sub.name == "faces") {
-          uint32_t nf = sub.u32(); mesh.faces.resize((size_t)nf * 3);
+          uint32_t nf = sub.count(nv > 65535 ? 12 : 6); mesh.faces.resize((size_t)nf * 3);
           if (nv > 65535) sub.raw(mesh.faces.data(), (size_t)nf * 12);                           // modelloader.d:602-605
           else { std::vector<uint16_t> s16((size_t)nf * 3); sub.raw(s16.data(), s16.size() * 2);
                  for (size_t i = 0; i < s16.size(); i++) mesh.faces[i] = s16[i]; }
@@ -123,14 +129,14 @@ void LoadFile(const std::string& path, ModelData& out) {
   }
   {  // nodes (modelloader.d:636-692)
     Cursor nd = file.chunk("nodes");
-    uint32_t n = nd.u32(); out.nodes.resize(n);
+    uint32_t n = nd.count(80); out.nodes.resize(n);                        // name length, transform, parent, two counts
     for (auto& node : out.nodes) {
       uint32_t len = nd.u32(); node.name = nd.str(len);
       nd.raw(node.transform, 64);
       uint32_t parent = nd.u32(); node.parent = parent == 0xFFFFFFFFu ? -1 : (int32_t)parent;
-      uint32_t nmesh = nd.u32(); node.meshes.resize(nmesh);
+      uint32_t nmesh = nd.count(4); node.meshes.resize(nmesh);
       for (auto& m : node.meshes) { m = nd.u32(); if (m >= out.meshes.size()) throw IoError("thModel: mesh index out of range"); }
-      uint32_t nch = nd.u32(); node.children.resize(nch);
+      uint32_t nch = nd.count(4); node.children.resize(nch);
       for (auto& ch : node.children) { ch = nd.u32(); if (ch >= n) throw IoError("thModel: child index out of range"); }
       if (node.parent >= (int32_t)n) throw IoError("thModel: parent index out of range");
     }

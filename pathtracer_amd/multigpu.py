@@ -5,8 +5,12 @@ The reference's only parallelism is disjoint 4-scanline tasks over one Pixel[] w
 
   split='bands'    rank r renders bands r, r+G, r+2G, ... of `band_rows` scanlines, all spp samples.
                    Streams are keyed (seed, pixel, sample), so the frame is bit-identical for any G.
-  split='samples'  every rank renders all pixels with its own slice of sample indices
-                   (sampleBase = rank * spp): G x spp samples per pixel in total (weak scaling).
+  split='samples'  every rank renders all pixels with its own residue class of sample indices
+                   (sampleBase = rank, sampleStride = G: sample k of a rank's pixel draws stream index
+                   rank + k * G): G x spp samples per pixel in total (weak scaling).  The classes stay
+                   disjoint over any number of passes and across checkpoint / resume, because k counts
+                   the samples the RANK's accumulator already holds -- so each rank keeps its own
+                   accumulator between passes and combines into a separate frame.
 
 Either way each rank ends with a full-frame (sum.rgb, n) accumulator that is zero where it did no work,
 and ONE reduce(sum) over RCCL/xGMI puts the frame together (x + 0 is exact, so the band split stays
@@ -42,7 +46,7 @@ def render_share(tracer, spp, rank, world, split='bands', band_rows=4):
         first, stride = band_share(rank, world)
         tracer.render_bands(band_rows, first, stride, spp)
     elif split == 'samples':
-        tracer.set_config(sample_base=rank * spp)
+        tracer.set_config(sample_base=rank, sample_stride=world)
         tracer.render_frame(spp)
     else:
         raise ValueError("split must be 'bands' or 'samples'")

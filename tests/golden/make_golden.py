@@ -44,6 +44,12 @@ def main():
         np.savez_compressed(os.path.join(HERE, 'oracle_%s_64x64.npz' % name), **out)
         print(name, 'hits', int((tri >= 0).sum()), 'tree==brute', bool(np.array_equal(tri, tri_t)),
               'mean radiance', float(px['color'].mean()), float(px1['color'].mean()))
+    import json
+    import oracle_digests
+    with open(os.path.join(HERE, 'oracle_freeze.json'), 'w') as f:
+        json.dump(oracle_digests.digests(), f, indent=1, sort_keys=True)
+        f.write('\n')
+    print('oracle_freeze.json written')
 
 
 if __name__ == '__main__':

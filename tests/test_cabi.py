@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(_lib.PtConfig) == 4 * 6 + 12 * 3 + 4 * 2 + 4 * 7          # all 4-byte fields, no padding
+    assert C.sizeof(_lib.PtConfig) == 4 * 6 + 12 * 3 + 4 * 2 + 4 * 8          # all 4-byte fields, no padding
     assert P.PIXEL_DTYPE.itemsize == 28 and P.MATERIAL_DTYPE.itemsize == 16   # rendering.d:24-37
     st = _lib.PtStats()
     assert C.sizeof(st) == 10 * 8 + 6 * 8 + 6 * 8 + 8 + 6 * 4 + 8

@@ -311,3 +311,26 @@ def test_quantised_nodes_on_extreme_scales(require_gpu, extent, size, offset):
     assert_hits_equal((tri, t, u, v), ref)
     assert np.array_equal(pt.hitsNothing(rays), o.trace_rays(rays, kind=1, use_tree=False)[0] < 0)
     assert (ref[0] >= 0).sum() > 50
+
+
+def test_direction_helpers_equal_oracle_bit_for_bit(require_gpu):
+    """angleToDirection / angleToLocalDirection (rendering.d:309-330) on the device against the oracle for the angle
+    ranges the integrator draws (psi in [0, 2 pi), phi in [0, pi/2] and the sun's [0.99 pi/2, pi/2]) and normals
+    on both sides of the |n.x| > 0.9 switch of the helper frame: the same bits, sin and cos included."""
+    rng = np.random.default_rng(11)
+    n = 200000
+    psi = rng.uniform(0, 2 * np.pi, n).astype(np.float32)
+    phi = np.where(rng.random(n) < 0.5, rng.uniform(0, np.pi / 2, n), rng.uniform(0.99 * np.pi / 2, np.pi / 2, n)).astype(np.float32)
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    nrm[: n // 4, 0] *= 8                                        # many normals with |n.x| > 0.9 after normalisation
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True).astype(np.float32)
+    nrm[::5] = 0                                                 # rows for angleToLocalDirection
+    edge = np.array([[0, 0], [np.pi / 2, 0], [0, np.pi], [np.pi / 2, 2 * np.pi], [np.pi / 4, np.pi / 2]], np.float32)
+    phi[:5], psi[:5] = edge[:, 0], edge[:, 1]
+    pt = P.PathTracer(8, 8, device=0)
+    got = pt.angle_directions(phi, psi, nrm)
+    ref = oracle_py.angle_directions(phi, psi, nrm)
+    assert (np.abs(nrm[:, 0]) > 0.9).sum() > 1000
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    unit = np.linalg.norm(got[np.abs(nrm).sum(1) > 0].astype(np.float64), axis=1)
+    assert np.abs(unit - 1).max() < 1e-5

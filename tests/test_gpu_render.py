@@ -1,9 +1,11 @@
 """GPU parity of the integrator (rendering.d:278-500) through the C ABI.
 
 Two kinds of comparison with the CPU oracle:
-  * same keyed RNG streams on both sides: images agree to floating-point tolerance (mode 0 without sky has no
-    sin/cos in it and agrees exactly; elsewhere libm vs device sin/cos differ by an ulp, which can flip a
-    visibility decision on a few pixels);
+  * same keyed RNG streams on both sides.  Mode 0 (the reference's HEAD) is bit-identical, sky and lights included:
+    every operation, sin / cos among them, has one fixed evaluation on both sides, and radiance is summed in the
+    source's order.  Mode 1: every ray, hit and visibility decision is identical (ray counts equal exactly); radiance
+    agrees to a few ulp, because the kernels carry a chain's throughput forward (T * color * L) where the recursion
+    multiplies on the way back (color * (Ld + color * (...))), and float products do not associate;
   * the reference-shaped oracle (Mt19937 per 4-scanline band, sphere-tree traversal): relative RMSE
     sqrt(mean((I_gpu - I_ref)^2)) / mean(I_ref) within 2x the RMSE between two oracle runs with different seeds
     at the same spp, and box-filtered bias within 1 %.
@@ -41,12 +43,8 @@ def test_image_equals_oracle_with_same_streams_mode0(require_gpu, name, flats):
     got = pt.read_pixels()
     ref = oracle_py.new_pixels(W * H); o.render_keyed(ref, 0, 16, nthreads=8)
     assert np.array_equal(got['n'], ref['n']) and (got['n'] == 16).all()
-    if not sky:
-        assert np.array_equal(got['sum'].view(np.uint32), ref['sum'].view(np.uint32))       # bit-identical
-        assert np.array_equal(got['color'].view(np.uint32), ref['color'].view(np.uint32))
-    else:
-        d = np.abs(got['color'] - ref['color']).max(1)
-        assert (d > 1e-4).mean() < 0.002 and rel_rmse(got['color'], ref['color']) < 2e-3
+    assert np.array_equal(got['sum'].view(np.uint32), ref['sum'].view(np.uint32))           # bit-identical
+    assert np.array_equal(got['color'].view(np.uint32), ref['color'].view(np.uint32))
     st = pt.stats()
     assert st.samples == W * H * 16 and st.raysPrimary == W * H * 16
 
@@ -57,16 +55,13 @@ def test_image_equals_golden_mode0(require_gpu, name):
     pt = make_tracer(name, 64, 64, has_sky=int(name != 'cornell-box'), seed=2024)
     pt.render_frame(64)
     got = pt.read_pixels()['color']
-    if name == 'cornell-box':
-        assert np.allclose(got, g['radiance_mode0_64spp'], rtol=1e-6, atol=1e-7)
-    else:
-        assert rel_rmse(got, g['radiance_mode0_64spp']) < 2e-3
+    assert np.array_equal(got.view(np.uint32), g['radiance_mode0_64spp'].view(np.uint32))
 
 
 @pytest.mark.parametrize('name', ['cornell-box', 'chest1'])
 def test_image_close_to_oracle_with_same_streams_mode1(require_gpu, name, flats):
-    """Indirect chains (rendering.d:376-394, 474-477): every bounce direction goes through sin/cos, so single
-    visibility decisions may flip; the images must still agree far below the Monte Carlo noise."""
+    """Indirect chains (rendering.d:376-394, 474-477): the same rays are traced and the same decisions taken as in the
+    oracle (counts equal exactly); radiance agrees to rounding (see the module docstring)."""
     W = H = 64
     sky = name != 'cornell-box'
     pt = make_tracer(name, W, H, has_sky=int(sky), mode=1, seed=2024)
@@ -76,14 +71,12 @@ def test_image_close_to_oracle_with_same_streams_mode1(require_gpu, name, flats)
     ref = oracle_py.new_pixels(W * H); _, cn = o.render_keyed(ref, 0, 16, nthreads=8)
     g = np.load(os.path.join(GOLDEN, 'oracle_%s_64x64.npz' % name))
     assert np.allclose(ref['color'], g['radiance_mode1_16spp'], rtol=1e-4, atol=1e-5)
-    o.configure(width=W, height=H, has_sky=sky, mode=1, seed=2025)
-    other = oracle_py.new_pixels(W * H); o.render_keyed(other, 0, 16, nthreads=8)
-    noise = rel_rmse(other['color'], ref['color'])
-    assert rel_rmse(got['color'], ref['color']) < 0.15 * noise
-    assert abs(got['color'].mean() - ref['color'].mean()) < 2e-3 * ref['color'].mean()
     st = pt.stats()
     rays = st.raysPrimary + st.raysLight + st.raysIndirect
-    assert abs(int(rays) - int(cn[0])) <= 2e-4 * int(cn[0]) and abs(int(st.raysOcclusion) - int(cn[1])) <= 2e-4 * max(1, int(cn[1]))
+    assert int(rays) == int(cn[0]) and int(st.raysOcclusion) == int(cn[1])
+    assert np.array_equal(got['n'], ref['n'])
+    assert np.allclose(got['sum'], ref['sum'], rtol=2e-5, atol=1e-7)
+    assert rel_rmse(got['color'], ref['color']) < 1e-6
     assert np.isfinite(got['sum']).all() and (got['sum'] >= (-0.0036 * 16 * 6 if sky else 0)).all()
 
 
@@ -166,7 +159,7 @@ def test_background_with_the_sun_disc_in_view_is_bit_identical(require_gpu):
         assert (got['n'] == spp).all()
         assert np.array_equal(got['sum'][bg].view(np.uint32), ref['sum'][bg].view(np.uint32))
         assert (got['sum'][bg].max(1) > 30 * spp * 0.5).any()              # the disc itself (radiance 30) is in there
-        assert rel_rmse(got['color'], ref['color']) < 2e-3
+        assert np.array_equal(got['sum'].view(np.uint32), ref['sum'].view(np.uint32))
         st = pt.stats()
         assert st.raysPrimary == W * H * spp and st.raysCulled >= (bg.sum() * spp if flags == 0 else 0)
 
@@ -205,11 +198,21 @@ def test_band_and_sample_splits_reassemble_bit_identically(require_gpu):
     assert (n == spp).all() and np.array_equal(s.view(np.uint32), want['sum'].view(np.uint32))
     rows = parts[1]['n'].reshape(H, W)
     assert (rows[4:8] == spp).all() and (rows[0:4] == 0).all() and (rows[8:12] == 0).all()
-    # sample slices: rank r renders samples [r*spp, (r+1)*spp)
-    a = make_tracer(name, W, H, has_sky=1, seed=8, sample_base=spp); a.render_frame(spp)
-    both = make_tracer(name, W, H, has_sky=1, seed=8); both.render_frame(2 * spp)
-    tot = want['sum'].astype(np.float64) + a.read_pixels()['sum'].astype(np.float64)
-    assert np.allclose(both.read_pixels()['sum'], tot, rtol=1e-6)
+    # sample slices: rank r of G renders sample indices r, r + G, r + 2G, ... (sampleBase = r, sampleStride = G), in
+    # two passes with its own accumulator, as a progressive multi-GPU render does; the index sets of the ranks are
+    # disjoint and together they are the 2 * G * spp indices one renderer draws with stride 1
+    G = 2
+    single = []                                                           # radiance of each sample index alone
+    for k in range(2 * G * 2):
+        t = make_tracer(name, W, H, has_sky=1, seed=8, sample_base=k); t.render_frame(1); single.append(t.read_pixels()['sum'])
+    for r in range(G):
+        t = make_tracer(name, W, H, has_sky=1, seed=8, sample_base=r, sample_stride=G)
+        t.render_frame(2); t.render_frame(2)
+        acc = np.zeros_like(single[0])
+        for k in range(r, 2 * G * 2, G):
+            acc = acc + single[k]
+        got = t.read_pixels()
+        assert (got['n'] == 4).all() and np.array_equal(got['sum'].view(np.uint32), acc.view(np.uint32))
 
 
 def test_pixel_checkpoint_roundtrip_and_resume(require_gpu, tmp_path):
@@ -237,8 +240,7 @@ def test_tonemap_equals_oracle(require_gpu):
     px = pt.read_pixels()
     rgb = pt.tonemap()
     ref = oracle_py.tonemap(px.view(oracle_py.PIXEL_DTYPE))
-    assert np.abs(rgb.astype(int) - ref.astype(int)).max() <= 1          # device powf vs libm powf
-    assert (rgb == ref).mean() > 0.99
+    assert np.array_equal(rgb, ref)                                      # bytes: bit-exact
     assert rgb.max() == 254                                              # saturated sky: 1.055f - 0.055f truncates to 254
 
 
@@ -277,7 +279,7 @@ def test_full_size_properties(require_gpu):
 def test_lights_and_sky_together_equal_oracle_with_same_streams(require_gpu, flags, mode):
     """A scene with a light group AND the sky: the light-sample kernel adds to a vertex's radiance first, the sun/sky
     kernel then reads, adds and writes it back (it may store it outright only when nothing precedes it).  Same streams
-    as the oracle; directions go through sin/cos, so single visibility decisions may flip (tolerance as for sky scenes)."""
+    as the oracle: mode 0 bit-identical, mode 1 identical rays and radiance to rounding."""
     fl = soup(1500, seed=21, size=12.0)                   # big triangles: most view rays hit, many shadow rays are blocked
     W, H = 96, 64
     cam = P.Camera(30.0, H / W).setTransform((250, 180, 160), (0, 0, 0), (0, 0, 1))
@@ -291,11 +293,8 @@ def test_lights_and_sky_together_equal_oracle_with_same_streams(require_gpu, fla
     assert np.array_equal(got['n'], ref['n'])
     st = pt.stats()
     assert st.raysLight > 0 and st.raysOcclusion > 0
+    assert int(st.raysPrimary + st.raysLight + st.raysIndirect) == int(cn[0]) and int(st.raysOcclusion) == int(cn[1])
     if mode == 0:
-        d = np.abs(got['color'] - ref['color']).max(1)
-        assert (d > 1e-4).mean() < 0.003 and rel_rmse(got['color'], ref['color']) < 3e-3
-        assert int(st.raysLight) == int(cn[0]) - W * H * spp and abs(int(st.raysOcclusion) - int(cn[1])) <= 2e-4 * int(cn[1])
+        assert np.array_equal(got['sum'].view(np.uint32), ref['sum'].view(np.uint32))
     else:
-        o.configure(width=W, height=H, has_sky=True, mode=mode, seed=6)
-        other = oracle_py.new_pixels(W * H); o.render_keyed(other, 0, spp, nthreads=8)
-        assert rel_rmse(got['color'], ref['color']) < 0.15 * rel_rmse(other['color'], ref['color'])
+        assert np.allclose(got['sum'], ref['sum'], rtol=2e-5, atol=1e-7)

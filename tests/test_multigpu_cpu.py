@@ -26,15 +26,20 @@ class FakeTracer:
 
     def __init__(self, acc):
         self.acc = acc.view(-1, 4)
-        self.sample_base = 0
+        self.sample_base, self.sample_stride = 0, 1
+        self.drawn = []                       # sample indices drawn for pixel 0, in order
 
-    def set_config(self, sample_base=0):
-        self.sample_base = sample_base
+    def set_config(self, sample_base=0, sample_stride=1):
+        self.sample_base, self.sample_stride = sample_base, sample_stride
 
     def _add(self, pixels, spp):
         a = self.acc.numpy()
         for s in range(spp):
-            a[pixels, :3] += fake_sample(pixels, np.full(len(pixels), self.sample_base + s))
+            # the library numbers a pixel's sample by what its accumulator already holds (PtConfig.sampleBase / sampleStride)
+            idx = self.sample_base + a[pixels, 3].astype(np.int64) * self.sample_stride
+            if len(pixels) and pixels[0] == 0:
+                self.drawn.append(int(idx[0]))
+            a[pixels, :3] += fake_sample(pixels, idx)
             a[pixels, 3] += 1
 
     def render_frame(self, spp):
@@ -52,8 +57,7 @@ def expected(split, world):
     if split == 'bands':
         t.render_frame(SPP)
     else:
-        for r in range(world):
-            t.set_config(sample_base=r * SPP); t.render_frame(SPP)
+        t.render_frame(SPP * world)           # indices 0 .. SPP * world - 1, each once
     return acc
 
 
@@ -110,3 +114,18 @@ def test_single_process_combine_is_identity():
     assert multigpu.combine(acc, None) is acc
     with pytest.raises(ValueError):
         multigpu.render_share(FakeTracer(torch.zeros(W * H * 4)), 1, 0, 1, split='tiles')
+
+
+def test_sample_split_draws_disjoint_indices_over_several_passes():
+    """Progressive rendering with the sample split: each rank keeps its own accumulator, and over P passes the G ranks
+    together draw every index in [0, P * G * spp) exactly once (a slice [rank * spp, (rank + 1) * spp) per pass would
+    replay indices from the second pass on)."""
+    world, passes = 3, 4
+    drawn = []
+    for rank in range(world):
+        t = FakeTracer(torch.zeros(W * H * 4))
+        for _ in range(passes):
+            multigpu.render_share(t, SPP, rank, world, split='samples')
+        assert len(t.drawn) == passes * SPP and all(i % world == rank for i in t.drawn)
+        drawn += t.drawn
+    assert sorted(drawn) == list(range(passes * world * SPP))

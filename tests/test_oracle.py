@@ -176,3 +176,57 @@ def test_tonemap_matches_formula():
     assert tuple(got[0]) == (0, 0, int(0.002 * 12.92 * 255))
     # 1.055f * 1 - 0.055f is 0.99999994f, and the cast truncates: a saturated channel is 254 on the scalar path
     assert tuple(got[2][:2]) == (254, 254)
+
+
+def test_oracle_is_frozen():
+    """Digests of the oracle's results on fixed inputs, one group per chosen thBase semantic (oracle.cpp S1..S14),
+    against tests/golden/oracle_freeze.json.  Nothing in the reference pins these results, so this is what keeps a
+    later change of a chosen semantic from moving the oracle and the product together unnoticed."""
+    import json
+    import oracle_digests
+    want = json.load(open(os.path.join(GOLDEN, 'oracle_freeze.json')))
+    got = oracle_digests.digests()
+    assert sorted(got) == sorted(want)
+    changed = [k for k in want if got[k] != want[k]]
+    assert not changed, 'oracle results changed: %s' % changed
+
+
+def _ulps(a, b):
+    return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+
+
+def test_fixed_sincos_and_pow_against_libm():
+    """S13 / S14: the fixed binary64 evaluations of sinf, cosf and powf(x, 1/2.4) stay within 1 ulp of the correctly
+    rounded value (and of this host's libm), on the ranges the integrator and the tone map use."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(0, 2 * np.pi, 400000), rng.uniform(0, np.pi / 2, 100000),
+                        [0.0, np.pi / 2, np.pi, 1.5 * np.pi, 2 * np.pi, np.pi / 2 * 0.99]]).astype(np.float32)
+    s, c = oracle_py.sincos(x)
+    exact_s = np.sin(x.astype(np.float64)).astype(np.float32); exact_c = np.cos(x.astype(np.float64)).astype(np.float32)
+    assert _ulps(s, exact_s).max() <= 1 and _ulps(c, exact_c).max() <= 1
+    assert (s != exact_s).mean() < 1e-4 and (c != exact_c).mean() < 1e-4
+    assert _ulps(s, np.sin(x)).max() <= 1 and _ulps(c, np.cos(x)).max() <= 1        # libm's float32 routines
+    y = np.concatenate([rng.uniform(0.0031308, 1.0, 400000), [0.0031309, 0.25, 0.5, 1.0]]).astype(np.float32)
+    p = oracle_py.pow_inv24(y)
+    exact_p = np.power(y.astype(np.float64), 1 / 2.4).astype(np.float32)
+    assert _ulps(p, exact_p).max() <= 1 and (p != exact_p).mean() < 1e-4
+    assert p[-1] == 1.0
+
+
+def test_keyed_sample_stride_interleaves_ranks(flats):
+    """Two renderers that each draw all pixels with sampleBase = rank, sampleStride = 2 use disjoint sample indices over
+    any number of passes: together, pass by pass, they draw exactly the samples one renderer draws with stride 1."""
+    W = H = 24
+    o = make_oracle(flats['teapot'], 'teapot', W, H, has_sky=True, seed=3)
+    one = oracle_py.new_pixels(W * H)
+    per_sample = []
+    for k in range(8):                                  # radiance of each single sample index 0..7
+        p = oracle_py.new_pixels(W * H); o.render_keyed(p, 0, 1, sample_base=k); per_sample.append(p['sum'].copy())
+    for rank in range(2):
+        acc = oracle_py.new_pixels(W * H)
+        for _ in range(2):                              # two passes of two samples each, n carried across passes
+            o.render_keyed(acc, 0, 2, sample_base=rank, sample_stride=2)
+        want = np.zeros_like(acc['sum'])
+        for k in range(rank, 8, 2):
+            want = want + per_sample[k]                 # same order of addition as the renderer: ascending index
+        assert np.array_equal(acc['sum'], want) and (acc['n'] == 4).all()

@@ -134,3 +134,37 @@ def test_reader_errors(tmp_path):
     assert 'old format' in str(e.value)                                          # modelloader.d:144-147
     with pytest.raises(ValueError):
         thmodel_ref.read_thmodel(str(trunc))
+
+
+def test_malformed_node_graphs_and_counts_are_refused(tmp_path):
+    """A file whose node graph is not a tree (the reference's findLeafs, scene.d:213-225, and its parent walk,
+    scene.d:258-262, would not terminate on it), or whose element counts exceed what the chunk holds, gives PT_E_IO
+    instead of a hang, a stack overflow or a huge allocation."""
+    import struct
+    pt = P.PathTracer(8, 8, device=-1)
+    data = open(model_path('chest1'), 'rb').read()
+    # node 0: parent none, no meshes, one child (node 1)
+    pat = struct.pack('<IIII', 0xFFFFFFFF, 0, 1, 1)
+    at = data.index(pat)
+    loop = bytearray(data); loop[at + 12:at + 16] = struct.pack('<I', 0)           # node 0 lists itself as its child
+    p = tmp_path / 'childloop.thModel'; p.write_bytes(bytes(loop))
+    with pytest.raises(P.PtError) as e:
+        pt.Scene(str(p))
+    assert e.value.code == -4 and 'not a tree' in str(e.value)
+    # node 1 (the file's last 16 bytes: parent, mesh count, mesh index, child count) names itself as its parent
+    assert data[-16:] == struct.pack('<IIII', 0, 1, 0, 0)
+    par = bytearray(data); par[-16:-12] = struct.pack('<I', 1)
+    p = tmp_path / 'parentloop.thModel'; p.write_bytes(bytes(par))
+    with pytest.raises(P.PtError) as e:
+        pt.Scene(str(p))
+    assert e.value.code == -4 and 'cycle' in str(e.value)
+    # counts far beyond the payload: textures, vertices, faces, nodes
+    for marker, skip in ((b'\x08textures', 4), (b'\x08vertices', -4), (b'\x05faces', 4), (b'\x05nodes', 4)):
+        at = data.index(marker) + len(marker) + skip          # the count follows the chunk length (vertices: precedes the chunk)
+        if skip < 0:
+            at = data.index(marker) - 4
+        big = bytearray(data); big[at:at + 4] = struct.pack('<I', 0xFFFFFFF0)
+        p = tmp_path / 'big.thModel'; p.write_bytes(bytes(big))
+        with pytest.raises(P.PtError) as e:
+            pt.Scene(str(p))
+        assert e.value.code == -4, marker
