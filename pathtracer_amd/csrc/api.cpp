@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -67,6 +68,7 @@ struct PtHandle {
   ViewMasks masks() const { return maskUsable ? ViewMasks{dMask.as<uint32_t>(), dSkyMask.as<uint32_t>()} : ViewMasks{nullptr, nullptr}; }
   DevBuf bMetaDesc; std::vector<QMeta> metas;     // queue descriptors: device copy and host copy, stage-major
   Wavefront wf{}; uint32_t wfKinds = 0, wfRounds = 0;
+  bool noEvents = false;        // while set, no event is created or recorded
   // statistics
   PtStats st{};
   std::vector<EventPair> pending; std::vector<hipEvent_t> freeEvents;
@@ -124,8 +126,9 @@ hipEvent_t getEvent(PtHandle* h) {
 struct Timed {
   PtHandle* h; int kind; bool on; hipEvent_t a{}, b{};
   Timed(PtHandle* h_, int kind_, bool force = false) : h(h_), kind(kind_) {
-    on = (force || (h->cfg.flags & PT_FLAG_TIME_KERNELS)) && h->pending.size() < MAX_EVENT_PAIRS;
-    if (!on && (force || (h->cfg.flags & PT_FLAG_TIME_KERNELS))) h->eventOverflow = true;
+    const bool wanted = !h->noEvents && (force || (h->cfg.flags & PT_FLAG_TIME_KERNELS));
+    on = wanted && h->pending.size() < MAX_EVENT_PAIRS;
+    if (!on && wanted) h->eventOverflow = true;
     if (on) { a = getEvent(h); b = getEvent(h); HIPCHECK(hipEventRecord(a, h->stream)); }
     if (kind < PT_K_COUNT) h->st.kernelLaunches[kind]++;
   }
@@ -344,19 +347,22 @@ void launchShadowKinds(PtHandle* h, const LaunchCfg& lc, const DevCfg& dc, const
 
 // One wavefront batch: npix pixels x k samples.  Counter set s belongs to stage s: 0 = raygen, 1 = shading of the
 // view-ray hits, 2 + r = shading of the indirect hits of round r; a stage reads the ray queue its predecessor filled.
-void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm) {
-  Wavefront wf = h->wf;
+// Where a batch keeps its state: the handle's own buffers (ensureWavefront) or the static scratch array.
+struct WfState { Wavefront wf; const QMeta* hostMetas; const QMeta* devMetas; ViewMasks masks; };
+
+void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, const WfState& ws) {
+  Wavefront wf = ws.wf;
   const uint32_t perStage = 2 + PT_MAX_KINDS;
   const int kinds = (int)((dc.hasLights ? h->dsc.numLightGroups : 0) + (dc.hasSky ? 1 : 0));
-  const QMeta* desc = h->bMetaDesc.as<QMeta>();
+  const QMeta* desc = ws.devMetas;
   // stage s: 0 = raygen, 1 = view-ray hits, 2 + r = indirect hits of round r.  Per stage: extend reads the previous
   // stage's ray queue and fills the hit queue [0]; shade reads it and fills the ray queue [1] and shadow queues
   // [2 + kind]; a scan after each producer makes its queues readable.
   auto bind = [&](uint32_t stage) {
-    wf.rayIn = h->metas[(size_t)(stage - 1) * perStage + 1];
-    wf.hitQ = h->metas[(size_t)stage * perStage];
-    wf.rayOut = h->metas[(size_t)stage * perStage + 1];
-    for (int k = 0; k < PT_MAX_KINDS; k++) wf.sh[k] = h->metas[(size_t)stage * perStage + 2 + k];
+    wf.rayIn = ws.hostMetas[(size_t)(stage - 1) * perStage + 1];
+    wf.hitQ = ws.hostMetas[(size_t)stage * perStage];
+    wf.rayOut = ws.hostMetas[(size_t)stage * perStage + 1];
+    for (int k = 0; k < PT_MAX_KINDS; k++) wf.sh[k] = ws.hostMetas[(size_t)stage * perStage + 2 + k];
   };
   auto scan = [&](size_t first, int n) {
     Timed t(h, PT_K_OTHER); launchScan(lc, desc + first, n, wf.taskCounters); t.done();
@@ -370,14 +376,14 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm) 
     launchShadowKinds(h, lc, dc, wf, primary);
   };
   uint32_t nslots = pm.npix * pm.k;
-  wf.rayOut = h->metas[1];
-  { Timed t(h, PT_K_OTHER); launchRaygen(lc, h->box, h->masks(), dc, pm, h->acc, nslots, wf); t.done(); }
+  wf.rayOut = ws.hostMetas[1];
+  { Timed t(h, PT_K_OTHER); launchRaygen(lc, h->box, ws.masks, dc, pm, h->acc, nslots, wf); t.done(); }
   scan(1, 1);
   stage(1, true);
   h->st.raysPrimary += nslots; h->st.samples += nslots;
   if (dc.mode == 1)      // depth 0..maxDepth can still spawn a ray (the check is depth > maxDepth, rendering.d:380)
     for (uint32_t round = 0; round <= dc.maxDepth; round++) stage(round + 2, false);
-  { Timed t(h, PT_K_ACCUM); launchAccumulate(lc, h->masks(), dc, pm, h->acc, wf, h->dsc); t.done(); }
+  { Timed t(h, PT_K_ACCUM); launchAccumulate(lc, ws.masks, dc, pm, h->acc, wf, h->dsc); t.done(); }
   HIPCHECK(hipGetLastError());
 }
 
@@ -394,12 +400,15 @@ void chooseTiling(PixMap& pm, uint32_t W, bool wholeRows) {
   pm.divTilesPerRow = makeFastDiv(pm.tilesPerRow);
 }
 
-void renderPixels(PtHandle* h, PixMap base, uint64_t totalPix, uint32_t spp) {
+// external: the batch state to use instead of the handle's own (the caller has laid it out); nothing is allocated,
+// built on the host or timed with events on that path.
+void renderPixels(PtHandle* h, PixMap base, uint64_t totalPix, uint32_t spp, const WfState* external = nullptr,
+                  uint32_t maxGroups = 0) {
   if (!h->haveScene) fail(PT_E_STATE, "no scene: call ptgpu_upload_scene or ptgpu_load_thmodel first");
   if (!h->haveCamera) fail(PT_E_STATE, "no camera: call ptgpu_set_camera or ptgpu_camera_look_at first");
   if (totalPix == 0 || spp == 0) return;
-  ensureWavefront(h);
-  if (h->maskDirty) {
+  if (!external) ensureWavefront(h);
+  if (!external && h->maskDirty) {
     std::vector<uint32_t> bits, sky;
     h->maskUsable = !(h->cfg.flags & PT_FLAG_NO_COVERAGE_MASK) &&
                     buildCoverageMask(h->flat, h->cam, h->cfg.width, h->cfg.height, bits, sky);
@@ -412,10 +421,13 @@ void renderPixels(PtHandle* h, PixMap base, uint64_t totalPix, uint32_t spp) {
     h->maskDirty = false;
   }
   DevCfg dc = makeDevCfg(h); LaunchCfg lc = makeLaunchCfg(h);
+  lc.maxGroups = maxGroups;
+  WfState own{h->wf, h->metas.data(), h->bMetaDesc.as<QMeta>(), h->masks()};
+  const WfState& ws = external ? *external : own;
   Timed span(h, KIND_RENDER, true);
   uint32_t W = h->cfg.width;
   bool wholeRows = (base.bandPix != 0 || base.offset % W == 0) && totalPix % W == 0;
-  uint64_t cap = h->wf.capSlots;
+  uint64_t cap = ws.wf.capSlots;
   uint64_t chunk = std::min<uint64_t>(cap, totalPix);
   if (wholeRows && chunk < totalPix && chunk >= 8ull * W) chunk -= chunk % (8ull * W);     // chunks of whole 8-row strips
   base.divBand = makeFastDiv(base.bandPix);
@@ -426,7 +438,7 @@ void renderPixels(PtHandle* h, PixMap base, uint64_t totalPix, uint32_t spp) {
       PixMap pm = base; pm.lpBase = (uint32_t)lp0; pm.npix = npix; pm.k = std::min(kmax, spp - s0);
       pm.divNpix = makeFastDiv(npix);
       chooseTiling(pm, W, wholeRows);
-      renderBatch(h, dc, lc, pm);
+      renderBatch(h, dc, lc, pm, ws);
     }
   }
   span.done();

@@ -168,7 +168,9 @@ PT_HD bool envDirect(const DevCfg& cfg, const DevScene& sc, bool primary) {
   return primary && cfg.hasSky && !(cfg.hasLights && sc.numLightGroups);
 }
 
-struct LaunchCfg { int device; int numCUs; bool countVisits; hipStream_t stream; };
+// maxGroups != 0 bounds the workgroups of a traversal launch (extend's hit queue needs PT_HIT_SLACK spare entries
+// per workgroup: a caller with a small hit queue launches fewer).
+struct LaunchCfg { int device; int numCUs; bool countVisits; hipStream_t stream; uint32_t maxGroups = 0; };
 
 // ---- wavefront stages (all asynchronous on lc.stream) ----
 // masks.covered == null: cull by the scene box
@@ -199,6 +201,8 @@ void launchHitsNothing(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cf
                        uint8_t* out, unsigned long long* stats);
 void launchTonemap(const LaunchCfg& lc, const float4* acc, uint32_t pixelOffset, uint32_t count, uint8_t* rgb);
 void launchAngleDirections(const LaunchCfg& lc, const float* in5, uint32_t n, float* out3);
+// Writes n queue descriptors over the counter words at `words` (PT_QMETA_WORDS each), as the host lays them out.
+void launchInitMetas(const LaunchCfg& lc, QMeta* desc, uint32_t* words, uint32_t n);
 void launchRngStream(const LaunchCfg& lc, uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n,
                      uint32_t* out);
 

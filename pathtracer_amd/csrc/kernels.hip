@@ -1065,6 +1065,7 @@ Geo traversalGeo(const LaunchCfg& lc, const DevScene& sc, uint64_t maxItems) {
   else { perCU = std::max(1u, ldsWorkgroupsPerCU(sc.ldsBytes)); bs = perCU == 8 ? 256 : perCU == 4 ? 512 : 1024; }
   uint64_t want = (maxItems + bs - 1) / bs;
   uint64_t cap = (uint64_t)lc.numCUs * perCU;
+  if (lc.maxGroups) cap = std::min<uint64_t>(cap, lc.maxGroups);
   g.block = dim3(bs); g.grid = dim3((unsigned)std::max<uint64_t>(1, std::min(want, cap)));
   return g;
 }
@@ -1193,6 +1194,17 @@ void launchTonemap(const LaunchCfg& lc, const float4* acc, uint32_t pixelOffset,
 
 void launchAngleDirections(const LaunchCfg& lc, const float* in5, uint32_t n, float* out3) {
   hipLaunchKernelGGL(k_angle_directions, dim3((n + 255) / 256), dim3(256), 0, lc.stream, in5, n, out3);
+}
+
+__global__ void k_init_metas(QMeta* desc, uint32_t* words, uint32_t n) {
+  uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n) return;
+  uint32_t* p = words + (size_t)m * PT_QMETA_WORDS;
+  QMeta q; q.count = p; q.prefix = p + PT_SEGS; q.start = p + 2 * PT_SEGS + 2;
+  desc[m] = q;
+}
+void launchInitMetas(const LaunchCfg& lc, QMeta* desc, uint32_t* words, uint32_t n) {
+  hipLaunchKernelGGL(k_init_metas, dim3((n + 255) / 256), dim3(256), 0, lc.stream, desc, words, n);
 }
 
 void launchRngStream(const LaunchCfg& lc, uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n, uint32_t* out) {

@@ -24,6 +24,37 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs an MI355X (run with -m gpu on the GPU box)')
 
 
+# Output of the native headless driver (csrc/headless_main.cpp), run once as a child process at session start: a
+# process that has already touched the GPU must not start other programs on this pool, so it cannot be started from
+# inside a GPU test.  None where there is no GPU or the driver is not built.
+HEADLESS = None
+HEADLESS_ARGS = dict(model='cornell-box', W=320, H=240, passes=4, seed=12)
+
+
+def run_headless(out_dir):
+    """ptgpu_headless on the cornell box at the reference's default frame size (rendering.d:19-20), 1 sample per
+    pass as main.d:273-287 does; returns its exit code, stdout and the paths of the PPM and project file it wrote."""
+    import subprocess
+    exe = os.path.join(ROOT, 'pathtracer_amd', 'ptgpu_headless')
+    a = HEADLESS_ARGS
+    ppm, proj = os.path.join(out_dir, 'headless.ppm'), os.path.join(out_dir, 'sponza.project')
+    cmd = [exe, os.path.join(MODELS, a['model'] + '.thModel'), '--size', str(a['W']), str(a['H']), '--passes', str(a['passes']),
+           '--seed', str(a['seed']), '--out', ppm, '--project', proj]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, text=True)
+    return dict(rc=r.returncode, stdout=r.stdout, ppm=ppm, project=proj)
+
+
+def pytest_sessionstart(session):
+    global HEADLESS
+    exe = os.path.join(ROOT, 'pathtracer_amd', 'ptgpu_headless')
+    if os.path.exists('/dev/kfd') and os.path.exists(exe):
+        import tempfile
+        try:
+            HEADLESS = run_headless(tempfile.mkdtemp(prefix='ptgpu_headless_'))
+        except Exception as e:                                    # reported by the test that looks at it
+            HEADLESS = dict(rc=-1, stdout='could not run: %r' % (e,), ppm=None, project=None)
+
+
 def model_path(name):
     return os.path.join(MODELS, name + '.thModel')
 
