@@ -142,6 +142,19 @@ int ptgpu_render(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount, uint32_
 int ptgpu_render_bands(PtHandle* h, uint32_t bandRows, uint32_t bandFirst, uint32_t bandStride, uint32_t spp);
 int ptgpu_synchronize(PtHandle* h);
 
+/* ptgpu_render for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same result as ptgpu_render for the same
+ * window and spp, bit for bit, but the wavefront state (ray, hit and shadow queues, per-sample radiance, queue
+ * counters) lives in a static device array of PT_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds for
+ * the life of the process, and the call makes no hipMalloc / hipFree, creates no event and builds nothing on the
+ * host.  The whole window is ONE batch: pixelCount * spp must fit the array for the handle's scene and configuration
+ * (mode 0: 655360 samples for a scene without light groups, 458752 with one; mode 1 with five chains: 65536); a larger request fails with PT_E_INVALID and a message
+ * that states the limit.  The view-ray masks are used when an earlier ptgpu_render built them for the current
+ * camera, otherwise the rays are culled by the scene's bounding box (same image).  All calls on one GPU share the
+ * array: calls that overlap in time on one GPU (two streams, two handles) race; serialise them. */
+#define PT_NOALLOC_SCRATCH_BYTES (96u << 20)
+int ptgpu_render_noalloc(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount, uint32_t spp);
+
 /* Pixel[] access for drawScreen (main.d:275) and the project file (main.d:227-234, 333-340). */
 int ptgpu_read_pixels(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount, PtPixel* out);
 int ptgpu_write_pixels(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount, const PtPixel* in);

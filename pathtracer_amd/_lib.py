@@ -46,6 +46,7 @@ SYMBOLS = {
     'ptgpu_set_camera': (_I, [_VP, _VP, _VP, _VP, _VP, _F, _F]),
     'ptgpu_camera_look_at': (_I, [_VP, _F, _F, _VP, _VP, _VP, _VP]),
     'ptgpu_render': (_I, [_VP, _U32, _U32, _U32]),
+    'ptgpu_render_noalloc': (_I, [_VP, _U32, _U32, _U32]),
     'ptgpu_render_bands': (_I, [_VP, _U32, _U32, _U32, _U32]),
     'ptgpu_synchronize': (_I, [_VP]),
     'ptgpu_read_pixels': (_I, [_VP, _U32, _U32, _VP]),

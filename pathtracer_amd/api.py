@@ -173,6 +173,10 @@ class PathTracer:
 
     render = computeOutputColor
 
+    def render_noalloc(self, pixelOffset, pixelCount, spp=1):
+        """computeOutputColor for callers that cannot allocate: one batch in the library's static scratch buffer."""
+        self._check(self.lib.ptgpu_render_noalloc(self.h, pixelOffset, pixelCount, spp))
+
     def render_frame(self, spp):
         self.computeOutputColor(0, self.width * self.height, spp)
 

@@ -42,6 +42,30 @@ struct DevBuf {
   template <typename T> T* as() const { return (T*)p; }
 };
 
+// Wavefront state of ptgpu_render_noalloc: queues, per-slot records and queue counters of ONE batch, in device
+// memory that exists from the moment the code object is loaded, so that the call itself allocates nothing.  Every
+// device the library runs on holds its own copy until the process ends.  `scratch` names the array for
+// hipGetSymbolAddress only; the address host code works with is the per-device pointer taken from it at set-up.
+constexpr size_t PT_NOALLOC_BYTES = (size_t)PT_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[PT_NOALLOC_BYTES];
+
+constexpr int PT_MAX_DEVICES = 64;
+void* g_scratchPtr[PT_MAX_DEVICES] = {};
+std::mutex g_scratchMu;
+
+// Address of `scratch` on the current device (which must be `device`); looked up once per device.
+void* scratchOnDevice(int device) {
+  if (device < 0 || device >= PT_MAX_DEVICES) fail(PT_E_INVALID, "device ordinal beyond " + std::to_string(PT_MAX_DEVICES - 1));
+  std::lock_guard<std::mutex> lk(g_scratchMu);
+  if (!g_scratchPtr[device]) {
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) fail(PT_E_DEVICE, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+    g_scratchPtr[device] = p;
+  }
+  return g_scratchPtr[device];
+}
+
 struct EventPair { hipEvent_t a, b; int kind; };
 constexpr int KIND_RENDER = PT_K_COUNT;       // span of one ptgpu_render call
 constexpr size_t MAX_EVENT_PAIRS = 16384;
@@ -68,7 +92,10 @@ struct PtHandle {
   ViewMasks masks() const { return maskUsable ? ViewMasks{dMask.as<uint32_t>(), dSkyMask.as<uint32_t>()} : ViewMasks{nullptr, nullptr}; }
   DevBuf bMetaDesc; std::vector<QMeta> metas;     // queue descriptors: device copy and host copy, stage-major
   Wavefront wf{}; uint32_t wfKinds = 0, wfRounds = 0;
-  bool noEvents = false;        // while set, no event is created or recorded
+  // ptgpu_render_noalloc: address of the static scratch array on this handle's device, and the host copy of the
+  // queue descriptors laid over it (sized at creation for the largest maxDepth, so that the call allocates nothing)
+  unsigned char* scratchDev = nullptr; std::vector<QMeta> metasNoAlloc;
+  bool noEvents = false;        // set while ptgpu_render_noalloc runs: no event is created or recorded
   // statistics
   PtStats st{};
   std::vector<EventPair> pending; std::vector<hipEvent_t> freeEvents;
@@ -483,6 +510,8 @@ int ptgpu_create(const PtConfig* cfg, PtHandle** out) {
     h->accOwn.alloc(h->accBytes); h->acc = h->accOwn.as<float4>();
     HIPCHECK(hipMemset(h->acc, 0, h->accBytes));
     h->bStats.alloc(STAT_COUNT * 8); HIPCHECK(hipMemset(h->bStats.p, 0, STAT_COUNT * 8));
+    h->scratchDev = (unsigned char*)scratchOnDevice(c.device);
+    h->metasNoAlloc.resize((size_t)(64 + 4) * (2 + PT_MAX_KINDS));        // maxDepth <= 64 (validateConfig)
   });
   if (rc != PT_OK) { delete h; return rc; }
   *out = h; return PT_OK;
@@ -612,6 +641,94 @@ int ptgpu_render(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount, uint32_
     useDevice(h);
     PixMap pm{}; pm.offset = pixelOffset;
     renderPixels(h, pm, pixelCount, spp);
+  });
+}
+
+// Largest batch of ptgpu_render_noalloc for the handle's current scene and configuration, and where its pieces lie
+// in the scratch array (offsets in bytes, each a multiple of 256).
+namespace {
+struct NoAllocLayout {
+  size_t slotQ, hitA, hitB, rayO, rayD, Lacc, thr, rng, shO, shD, shW, shX, words, desc, total;
+  uint32_t capSlots, capQueue, capHit, lanes, kinds, rounds;
+};
+constexpr uint32_t PT_NOALLOC_GROUPS = 128;      // traversal workgroups per launch: bounds the hit queue's slack
+
+NoAllocLayout layoutNoAlloc(const PtHandle* h, uint32_t capSlots) {
+  const PtConfig& c = h->cfg;
+  NoAllocLayout L{};
+  const uint32_t NI = c.mode == 1 ? c.numIndirect : 0;
+  L.capSlots = capSlots; L.lanes = 1 + NI; L.kinds = numKinds(h); L.rounds = c.mode == 1 ? c.maxDepth + 4 : 2;
+  const uint64_t capQueue = (uint64_t)capSlots * std::max(1u, NI);
+  uint64_t capHit = capQueue + (uint64_t)PT_NOALLOC_GROUPS * PT_HIT_SLACK;
+  capHit = (capHit + PT_SEGS - 1) / PT_SEGS * PT_SEGS;
+  if (capHit > 0x7FFFFFFFull) { L.total = ~(size_t)0; return L; }
+  L.capQueue = (uint32_t)capQueue; L.capHit = (uint32_t)capHit;
+  size_t at = 0;
+  auto piece = [&](uint64_t bytes) { size_t o = at; at += (size_t)((bytes + 255) / 256 * 256); return o; };
+  L.slotQ = piece((uint64_t)capSlots * 16);
+  L.hitA = piece(capHit * 16); L.hitB = piece(capHit * 16);
+  L.rayO = piece(NI ? capQueue * 16 : 16); L.rayD = piece(NI ? capQueue * 16 : 16);
+  L.Lacc = piece((uint64_t)L.lanes * capSlots * 16);
+  L.thr = piece(NI ? (uint64_t)L.lanes * capSlots * 16 : 16);
+  L.rng = piece(NI ? (uint64_t)L.lanes * capSlots * 8 : 16);
+  L.shO = piece((uint64_t)L.kinds * capQueue * 16); L.shD = piece((uint64_t)L.kinds * capQueue * 16);
+  L.shW = piece((uint64_t)L.kinds * capQueue * 16); L.shX = piece(capQueue * 16);
+  const uint64_t nMetas = (uint64_t)L.rounds * (2 + PT_MAX_KINDS);
+  L.words = piece(nMetas * PT_QMETA_WORDS * 4 + PT_TASK_COUNTERS * 4);
+  L.desc = piece(nMetas * sizeof(QMeta));
+  L.total = at;
+  return L;
+}
+}  // namespace
+
+int ptgpu_render_noalloc(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount, uint32_t spp) {
+  return guarded([&]() {
+    if (!h) fail(PT_E_INVALID, "null handle");
+    checkWindow(h, pixelOffset, pixelCount);
+    useDevice(h);
+    if (!h->haveScene) fail(PT_E_STATE, "no scene: call ptgpu_upload_scene or ptgpu_load_thmodel first");
+    if (!h->haveCamera) fail(PT_E_STATE, "no camera: call ptgpu_set_camera or ptgpu_camera_look_at first");
+    if (pixelCount == 0 || spp == 0) return;
+    const uint64_t gran = 64ull * PT_SEGS;
+    const uint64_t nslots = (uint64_t)pixelCount * spp;
+    // the largest batch the scratch array holds for this scene and configuration
+    uint64_t maxSlots = 0;
+    for (uint64_t s = gran; s <= 0x40000000ull && layoutNoAlloc(h, (uint32_t)s).total <= PT_NOALLOC_BYTES; s += gran) maxSlots = s;
+    if (nslots > maxSlots)
+      fail(PT_E_INVALID, "ptgpu_render_noalloc: pixelCount * spp = " + std::to_string(nslots) + " exceeds the " +
+                             std::to_string(maxSlots) + " samples per call that the " + std::to_string(PT_NOALLOC_BYTES >> 20) +
+                             " MiB static scratch buffer holds for this scene and configuration (mode, numIndirect, light groups); "
+                             "split the window or use ptgpu_render");
+    const NoAllocLayout L = layoutNoAlloc(h, (uint32_t)((nslots + gran - 1) / gran * gran));
+    unsigned char* base = h->scratchDev;
+    WfState ws{};
+    Wavefront& w = ws.wf;
+    w.slotQ = (float4*)(base + L.slotQ); w.hitA = (float4*)(base + L.hitA); w.hitB = (float4*)(base + L.hitB);
+    w.rayO = (float4*)(base + L.rayO); w.rayD = (float4*)(base + L.rayD); w.Lacc = (float4*)(base + L.Lacc);
+    w.thr = (float4*)(base + L.thr); w.rng = (uint2*)(base + L.rng);
+    w.shO = (float4*)(base + L.shO); w.shD = (float4*)(base + L.shD); w.shW = (float4*)(base + L.shW); w.shX = (float4*)(base + L.shX);
+    w.stats = h->bStats.as<unsigned long long>();
+    w.capSlots = L.capSlots; w.capQueue = L.capQueue; w.capHit = L.capHit; w.lanes = L.lanes;
+    uint32_t* words = (uint32_t*)(base + L.words);
+    const size_t nMetas = (size_t)L.rounds * (2 + PT_MAX_KINDS);
+    for (size_t m = 0; m < nMetas; m++) {
+      uint32_t* p = words + m * PT_QMETA_WORDS;
+      h->metasNoAlloc[m] = QMeta{p, p + PT_SEGS, p + 2 * PT_SEGS + 2};
+    }
+    w.taskCounters = words + nMetas * PT_QMETA_WORDS;
+    ws.hostMetas = h->metasNoAlloc.data(); ws.devMetas = (const QMeta*)(base + L.desc);
+    // masks built for the current scene and camera are used; none is built here (that would allocate): the view rays
+    // are then culled by the scene's bounding box, which gives the same image
+    ws.masks = (!h->maskDirty && h->maskUsable) ? h->masks() : ViewMasks{nullptr, nullptr};
+    // the array keeps the last call's contents (of this or any other handle on the device): counters start at zero
+    HIPCHECK(hipMemsetAsync(words, 0, nMetas * PT_QMETA_WORDS * 4 + PT_TASK_COUNTERS * 4, h->stream));
+    LaunchCfg lc = makeLaunchCfg(h);
+    launchInitMetas(lc, (QMeta*)(base + L.desc), words, (uint32_t)nMetas);
+    HIPCHECK(hipGetLastError());
+    PixMap pm{}; pm.offset = pixelOffset;
+    h->noEvents = true;
+    try { renderPixels(h, pm, pixelCount, spp, &ws, PT_NOALLOC_GROUPS); } catch (...) { h->noEvents = false; throw; }
+    h->noEvents = false;
   });
 }
 
