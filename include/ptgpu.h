@@ -161,6 +161,18 @@ int ptgpu_write_pixels(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount, c
 int ptgpu_clear_pixels(PtHandle* h);
 /* drawScreen's scalar path on the device: saturate -> sRGB OETF -> (ubyte)(x*255), 3 bytes per pixel (main.d:82-95). */
 int ptgpu_tonemap(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount, uint8_t* rgb);
+/* The same in two halves, for the progressive loop (main.d:273-287: draw pass k, then render pass k + 1): begin queues
+ * the tone map behind the passes rendered so far and its copy to the host on a second stream, and returns; calls made
+ * before end (ptgpu_render of the next pass) run beside the copy; end waits until rgb holds the bytes.  One begin may
+ * be outstanding per handle.  rgb must stay valid until end. */
+int ptgpu_tonemap_begin(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount, uint8_t* rgb);
+int ptgpu_tonemap_end(PtHandle* h);
+/* Page-locked host memory for the caller's Pixel[] (NewArray!Pixel, main.d:175) and frame bytes: ptgpu_read_pixels,
+ * ptgpu_write_pixels and ptgpu_tonemap* copy straight into / out of such memory; any other buffer goes through a
+ * page-locked staging buffer of the handle and one more memcpy.  (Page-locking memory the caller already owns,
+ * hipHostRegister, is refused by the host driver this was developed on; hence allocation.) */
+int ptgpu_host_alloc(PtHandle* h, uint64_t bytes, void** out);
+int ptgpu_host_free(PtHandle* h, void* p);
 
 /* Scene.trace (scene.d:681-743) for caller-supplied rays, 6 floats each (pos, dir): closest front-face hit.
  * Outputs may be NULL.  triId = -1 and t = FLT_MAX on a miss. */

@@ -53,6 +53,10 @@ SYMBOLS = {
     'ptgpu_write_pixels': (_I, [_VP, _U32, _U32, _VP]),
     'ptgpu_clear_pixels': (_I, [_VP]),
     'ptgpu_tonemap': (_I, [_VP, _U32, _U32, _VP]),
+    'ptgpu_tonemap_begin': (_I, [_VP, _U32, _U32, _VP]),
+    'ptgpu_tonemap_end': (_I, [_VP]),
+    'ptgpu_host_alloc': (_I, [_VP, C.c_uint64, C.POINTER(_VP)]),
+    'ptgpu_host_free': (_I, [_VP, _VP]),
     'ptgpu_scene_trace': (_I, [_VP, _VP, _U32, _VP, _VP, _VP, _VP, _VP]),
     'ptgpu_scene_trace_tex': (_I, [_VP, _VP, _U32, _I, _VP, _VP, _VP, _VP]),
     'ptgpu_set_texcoords': (_I, [_VP, _VP]),

@@ -206,6 +206,32 @@ class PathTracer:
         self._check(self.lib.ptgpu_tonemap(self.h, offset, count, _ptr(out)))
         return out
 
+    def tonemap_begin(self, out, offset=0):
+        """First half of tonemap(): queues the tone map and its copy into `out` (uint8, count x 3, kept alive by the
+        caller) and returns; tonemap_end() waits for the bytes.  Passes rendered in between overlap the copy."""
+        assert out.dtype == np.uint8 and out.flags['C_CONTIGUOUS'] and out.size % 3 == 0
+        self._check(self.lib.ptgpu_tonemap_begin(self.h, offset, out.size // 3, _ptr(out)))
+
+    def tonemap_end(self):
+        self._check(self.lib.ptgpu_tonemap_end(self.h))
+
+    def host_array(self, shape, dtype):
+        """A numpy array in page-locked memory of the library (frame transfers copy straight into / out of it).
+        Freed by host_free(array); must not be used afterwards."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        self._check(self.lib.ptgpu_host_alloc(self.h, max(1, n), C.byref(p)))
+        buf = (C.c_uint8 * n).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        arr[...] = np.zeros((), dtype)
+        self._host_ptrs = getattr(self, '_host_ptrs', {}); self._host_ptrs[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, array):
+        p = self._host_ptrs.pop(array.ctypes.data)
+        self._check(self.lib.ptgpu_host_free(self.h, C.c_void_p(p)))
+
     # ------------------------------------------------------------------ Scene.trace / Scene.hitsNothing
     def trace(self, rays6):
         rays6 = np.ascontiguousarray(rays6, np.float32).reshape(-1, 6); n = len(rays6)

@@ -66,6 +66,29 @@ void* scratchOnDevice(int device) {
   return g_scratchPtr[device];
 }
 
+// Page-locked host memory that lives as long as the handle: what the frame crosses PCIe through when the caller's
+// own buffer is pageable (a pageable copy runs at a tenth of the link's rate).
+struct PinnedBuf {
+  void* p = nullptr; size_t bytes = 0;
+  void alloc(size_t n) {
+    if (n <= bytes && p) return;
+    release();
+    hipError_t e = hipHostMalloc(&p, n ? n : 16, hipHostMallocDefault);
+    if (e != hipSuccess) { p = nullptr; fail(PT_E_NOMEM, "hipHostMalloc(" + std::to_string(n) + " bytes): " + hipGetErrorString(e)); }
+    bytes = n ? n : 16;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
+  ~PinnedBuf() { release(); }
+};
+
+// Whether the device can copy straight into / out of p (page-locked memory of hipHostMalloc / ptgpu_host_alloc).
+bool isPinnedHost(const void* p) {
+  hipPointerAttribute_t a;
+  hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeHost;
+}
+
 struct EventPair { hipEvent_t a, b; int kind; };
 constexpr int KIND_RENDER = PT_K_COUNT;       // span of one ptgpu_render call
 constexpr size_t MAX_EVENT_PAIRS = 16384;
@@ -95,6 +118,11 @@ struct PtHandle {
   // ptgpu_render_noalloc: address of the static scratch array on this handle's device, and the host copy of the
   // queue descriptors laid over it (sized at creation for the largest maxDepth, so that the call allocates nothing)
   unsigned char* scratchDev = nullptr; std::vector<QMeta> metasNoAlloc;
+  // frame transfer: device-side records and bytes, page-locked staging, a second stream for copies that overlap the
+  // next pass, one event per tone-map buffer (two buffers alternate)
+  DevBuf dPixelRec, dRgb[2]; PinnedBuf pinPixels, pinRgb[2];
+  hipStream_t copyStream = nullptr; hipEvent_t evTone[2] = {nullptr, nullptr}, evCopy[2] = {nullptr, nullptr};
+  int toneNext = 0, tonePending = -1; uint8_t* toneDst = nullptr; size_t toneBytes = 0; bool toneDirect = false;
   bool noEvents = false;        // set while ptgpu_render_noalloc runs: no event is created or recorded
   // statistics
   PtStats st{};
@@ -510,6 +538,11 @@ int ptgpu_create(const PtConfig* cfg, PtHandle** out) {
     h->accOwn.alloc(h->accBytes); h->acc = h->accOwn.as<float4>();
     HIPCHECK(hipMemset(h->acc, 0, h->accBytes));
     h->bStats.alloc(STAT_COUNT * 8); HIPCHECK(hipMemset(h->bStats.p, 0, STAT_COUNT * 8));
+    HIPCHECK(hipStreamCreateWithFlags(&h->copyStream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) {
+      HIPCHECK(hipEventCreateWithFlags(&h->evTone[k], hipEventDisableTiming));
+      HIPCHECK(hipEventCreateWithFlags(&h->evCopy[k], hipEventDisableTiming));
+    }
     h->scratchDev = (unsigned char*)scratchOnDevice(c.device);
     h->metasNoAlloc.resize((size_t)(64 + 4) * (2 + PT_MAX_KINDS));        // maxDepth <= 64 (validateConfig)
   });
@@ -525,6 +558,8 @@ int ptgpu_destroy(PtHandle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (EventPair& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (hipEvent_t e : h->freeEvents) (void)hipEventDestroy(e);
+    if (h->copyStream) { (void)hipStreamSynchronize(h->copyStream); (void)hipStreamDestroy(h->copyStream); }
+    for (int k = 0; k < 2; k++) { if (h->evTone[k]) (void)hipEventDestroy(h->evTone[k]); if (h->evCopy[k]) (void)hipEventDestroy(h->evCopy[k]); }
     if (h->ownStream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
   });
@@ -758,14 +793,18 @@ int ptgpu_read_pixels(PtHandle* h, uint32_t off, uint32_t count, PtPixel* out) {
   return guarded([&]() {
     if (!h || (!out && count)) fail(PT_E_INVALID, "null argument");
     checkWindow(h, off, count); useDevice(h);
-    std::vector<float> tmp((size_t)count * 4);
-    HIPCHECK(hipMemcpyAsync(tmp.data(), h->acc + off, (size_t)count * 16, hipMemcpyDeviceToHost, h->stream));
+    if (!count) return;
+    // the 28-byte records are made on the device (pixel.color = pixel.sum / pixel.n, an IEEE division there as here)
+    // and cross PCIe once: straight into `out` when the caller page-locked it, else through the handle's staging
+    const size_t bytes = (size_t)count * sizeof(PtPixel);
+    h->dPixelRec.alloc(bytes);
+    launchPackPixels(makeLaunchCfg(h), h->acc, off, count, h->dPixelRec.as<float>());
+    HIPCHECK(hipGetLastError());
+    const bool direct = isPinnedHost(out);
+    if (!direct) h->pinPixels.alloc(bytes);
+    HIPCHECK(hipMemcpyAsync(direct ? (void*)out : h->pinPixels.p, h->dPixelRec.p, bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
-    for (uint32_t i = 0; i < count; i++) {
-      const float* a = &tmp[(size_t)i * 4]; PtPixel& p = out[i];
-      p.sum[0] = a[0]; p.sum[1] = a[1]; p.sum[2] = a[2]; p.n = a[3];
-      for (int k = 0; k < 3; k++) p.color[k] = a[3] > 0.0f ? a[k] / a[3] : 0.0f;     // pixel.color = pixel.sum / pixel.n
-    }
+    if (!direct) std::memcpy(out, h->pinPixels.p, bytes);
   });
 }
 
@@ -773,11 +812,15 @@ int ptgpu_write_pixels(PtHandle* h, uint32_t off, uint32_t count, const PtPixel*
   return guarded([&]() {
     if (!h || (!in && count)) fail(PT_E_INVALID, "null argument");
     checkWindow(h, off, count); useDevice(h);
-    std::vector<float> tmp((size_t)count * 4);
-    for (uint32_t i = 0; i < count; i++) { tmp[4 * (size_t)i] = in[i].sum[0]; tmp[4 * (size_t)i + 1] = in[i].sum[1];
-                                           tmp[4 * (size_t)i + 2] = in[i].sum[2]; tmp[4 * (size_t)i + 3] = in[i].n; }
-    HIPCHECK(hipStreamSynchronize(h->stream));
-    HIPCHECK(hipMemcpy(h->acc + off, tmp.data(), (size_t)count * 16, hipMemcpyHostToDevice));
+    if (!count) return;
+    const size_t bytes = (size_t)count * sizeof(PtPixel);
+    h->dPixelRec.alloc(bytes);
+    const bool direct = isPinnedHost(in);
+    if (!direct) { HIPCHECK(hipStreamSynchronize(h->stream)); h->pinPixels.alloc(bytes); std::memcpy(h->pinPixels.p, in, bytes); }
+    HIPCHECK(hipMemcpyAsync(h->dPixelRec.p, direct ? (const void*)in : h->pinPixels.p, bytes, hipMemcpyHostToDevice, h->stream));
+    launchUnpackPixels(makeLaunchCfg(h), h->dPixelRec.as<float>(), off, count, h->acc);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(h->stream));       // `in` and the staging buffer may be reused when this returns
   });
 }
 
@@ -789,15 +832,79 @@ int ptgpu_clear_pixels(PtHandle* h) {
   });
 }
 
+namespace {
+// Tone map of a window into one of the handle's two device buffers on the render stream, then its copy to the host on
+// the copy stream, so that kernels queued on the render stream afterwards (the next pass) run beside the copy.
+void tonemapBegin(PtHandle* h, uint32_t off, uint32_t count, uint8_t* rgb) {
+  if (h->tonePending >= 0) fail(PT_E_STATE, "a ptgpu_tonemap_begin is outstanding: call ptgpu_tonemap_end first");
+  const int k = h->toneNext;
+  const size_t bytes = (size_t)count * 3;
+  h->dRgb[k].alloc(bytes);
+  h->toneDirect = isPinnedHost(rgb);
+  if (!h->toneDirect) h->pinRgb[k].alloc(bytes);
+  launchTonemap(makeLaunchCfg(h), h->acc, off, count, h->dRgb[k].as<uint8_t>());
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipEventRecord(h->evTone[k], h->stream));
+  HIPCHECK(hipStreamWaitEvent(h->copyStream, h->evTone[k], 0));
+  HIPCHECK(hipMemcpyAsync(h->toneDirect ? (void*)rgb : h->pinRgb[k].p, h->dRgb[k].p, bytes, hipMemcpyDeviceToHost, h->copyStream));
+  HIPCHECK(hipEventRecord(h->evCopy[k], h->copyStream));
+  h->tonePending = k; h->toneDst = rgb; h->toneBytes = bytes; h->toneNext = k ^ 1;
+}
+void tonemapEnd(PtHandle* h) {
+  if (h->tonePending < 0) fail(PT_E_STATE, "no ptgpu_tonemap_begin is outstanding");
+  const int k = h->tonePending;
+  h->tonePending = -1;
+  HIPCHECK(hipEventSynchronize(h->evCopy[k]));
+  if (!h->toneDirect) std::memcpy(h->toneDst, h->pinRgb[k].p, h->toneBytes);
+}
+}  // namespace
+
 int ptgpu_tonemap(PtHandle* h, uint32_t off, uint32_t count, uint8_t* rgb) {
   return guarded([&]() {
     if (!h || (!rgb && count)) fail(PT_E_INVALID, "null argument");
     checkWindow(h, off, count); useDevice(h);
     if (!count) return;
-    DevBuf d; d.alloc((size_t)count * 3);
-    launchTonemap(makeLaunchCfg(h), h->acc, off, count, d.as<uint8_t>());
-    HIPCHECK(hipMemcpyAsync(rgb, d.p, (size_t)count * 3, hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
+    tonemapBegin(h, off, count, rgb);
+    tonemapEnd(h);
+  });
+}
+
+int ptgpu_tonemap_begin(PtHandle* h, uint32_t off, uint32_t count, uint8_t* rgb) {
+  return guarded([&]() {
+    if (!h || !rgb) fail(PT_E_INVALID, "null argument");
+    checkWindow(h, off, count); useDevice(h);
+    if (!count) fail(PT_E_INVALID, "empty window");
+    tonemapBegin(h, off, count, rgb);
+  });
+}
+
+int ptgpu_tonemap_end(PtHandle* h) {
+  return guarded([&]() {
+    if (!h) fail(PT_E_INVALID, "null handle");
+    useDevice(h);
+    tonemapEnd(h);
+  });
+}
+
+int ptgpu_host_alloc(PtHandle* h, uint64_t bytes, void** out) {
+  return guarded([&]() {
+    if (!h || !out || !bytes) fail(PT_E_INVALID, "null argument");
+    *out = nullptr;
+    useDevice(h);
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); fail(PT_E_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+    *out = p;
+  });
+}
+
+int ptgpu_host_free(PtHandle* h, void* p) {
+  return guarded([&]() {
+    if (!h) fail(PT_E_INVALID, "null handle");
+    if (!p) return;
+    useDevice(h);
+    HIPCHECK(hipStreamSynchronize(h->stream)); HIPCHECK(hipStreamSynchronize(h->copyStream));
+    HIPCHECK(hipHostFree(p));
   });
 }
 

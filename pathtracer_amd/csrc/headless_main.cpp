@@ -3,6 +3,7 @@
 // tone map, total time, project file dump -- driving libptgpu through its C ABI instead of SDL + the D
 // task queue.  The image goes to a binary PPM instead of an SDL surface.
 #include "../../include/ptgpu.h"
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -19,7 +20,9 @@ static int usage() {
   std::fprintf(stderr,
                "usage: ptgpu_headless MODEL.thModel [--size W H] [--passes N] [--spp-per-pass K] [--from x y z] [--to x y z]\n"
                "         [--fov deg] [--sky] [--no-lights] [--mode 0|1] [--seed s] [--device d] [--out image.ppm]\n"
-               "         [--project file]   (raw Pixel[] as main.d:227-234 reads and main.d:333-340 writes)\n");
+               "         [--project file]   (raw Pixel[] as main.d:227-234 reads and main.d:333-340 writes)\n"
+               "         [--display sync|overlap]  tone map + copy the frame to the host after every pass, as drawScreen is\n"
+               "                                   called per pass (main.d:275); overlap: beside the next pass's rendering\n");
   return 2;
 }
 
@@ -31,7 +34,7 @@ static int usage() {
 
 int main(int argc, char** argv) {
   if (argc < 2) return usage();
-  std::string model = argv[1], out, project;
+  std::string model = argv[1], out, project, display;
   uint32_t W = 320, H = 240, passes = 16, sppPerPass = 1;        // rendering.d:19-20; one sample per pass (main.d:273-287)
   float from[3] = {-1, 26.5f, 10}, to[3] = {0, 0, 9}, up[3] = {0, 0, 1}, fov = 30.0f;   // rendering.d:76,81
   PtConfig cfg; std::memset(&cfg, 0, sizeof(cfg));
@@ -52,6 +55,7 @@ int main(int argc, char** argv) {
     else if (a == "--device") { need(1); cfg.device = std::atoi(argv[++i]); }
     else if (a == "--out") { need(1); out = argv[++i]; }
     else if (a == "--project") { need(1); project = argv[++i]; }
+    else if (a == "--display") { need(1); display = argv[++i]; if (display != "sync" && display != "overlap") return usage(); }
     else return usage();
   }
   cfg.width = W; cfg.height = H;
@@ -82,15 +86,39 @@ int main(int argc, char** argv) {
       if (got == npix) { CHECK(ptgpu_write_pixels(h, 0, npix, pixels.data())); std::printf("project file loaded\n"); }
     }
   }
+  // the frame as drawScreen would show it (main.d:31-99), in page-locked memory so that the device writes it directly
+  uint8_t* screen[2] = {nullptr, nullptr};
+  if (!display.empty())
+    for (auto& s : screen) { void* p = nullptr; CHECK(ptgpu_host_alloc(h, (uint64_t)npix * 3, &p)); s = (uint8_t*)p; }
+  std::vector<double> passSeconds;
   double startRendering = now(), startPass = startRendering;
+  bool pendingDraw = false;
   for (uint32_t progress = 1; progress <= passes; progress++) {                    // main.d:239-288
     CHECK(ptgpu_render(h, 0, npix, sppPerPass));
-    CHECK(ptgpu_synchronize(h));
+    if (display == "sync") {                                                       // render, then draw (main.d:273-287)
+      CHECK(ptgpu_tonemap(h, 0, npix, screen[0]));
+    } else if (display == "overlap") {                                             // draw pass k beside rendering pass k + 1
+      if (pendingDraw) CHECK(ptgpu_tonemap_end(h));
+      CHECK(ptgpu_tonemap_begin(h, 0, npix, screen[progress & 1]));
+      pendingDraw = true;
+    } else {
+      CHECK(ptgpu_synchronize(h));
+    }
     double endPass = now();
     std::printf("pass %u done in %f seconds\n", progress, endPass - startPass);   // main.d:279
+    passSeconds.push_back(endPass - startPass);
     startPass = endPass;
   }
+  if (pendingDraw) CHECK(ptgpu_tonemap_end(h));
+  CHECK(ptgpu_synchronize(h));
   std::printf("Rendering took %f seconds\n", now() - startRendering);             // main.d:331
+  if (passSeconds.size() > 2) {                 // steady state: the first pass builds masks and allocates
+    std::vector<double> s(passSeconds.begin() + 1, passSeconds.end());
+    std::sort(s.begin(), s.end());
+    std::printf("pass_ms median %.4f min %.4f (%ux%u, %u spp per pass, display %s)\n", 1e3 * s[s.size() / 2], 1e3 * s[0], W, H,
+                sppPerPass, display.empty() ? "none" : display.c_str());
+  }
+  for (auto& s : screen) CHECK(ptgpu_host_free(h, s));
   CHECK(ptgpu_get_stats(h, &st));
   uint64_t rays = st.raysPrimary + st.raysLight + st.raysIndirect + st.raysOcclusion;
   std::printf("%llu rays, %.1f Mrays/s (device time %.3f ms)\n", (unsigned long long)rays,

@@ -200,6 +200,8 @@ void launchTraceTex(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, 
 void launchHitsNothing(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const float* rays6, uint32_t count,
                        uint8_t* out, unsigned long long* stats);
 void launchTonemap(const LaunchCfg& lc, const float4* acc, uint32_t pixelOffset, uint32_t count, uint8_t* rgb);
+void launchPackPixels(const LaunchCfg& lc, const float4* acc, uint32_t pixelOffset, uint32_t count, float* out7);
+void launchUnpackPixels(const LaunchCfg& lc, const float* in7, uint32_t pixelOffset, uint32_t count, float4* acc);
 void launchAngleDirections(const LaunchCfg& lc, const float* in5, uint32_t n, float* out3);
 // Writes n queue descriptors over the counter words at `words` (PT_QMETA_WORDS each), as the host lays them out.
 void launchInitMetas(const LaunchCfg& lc, QMeta* desc, uint32_t* words, uint32_t n);

@@ -1035,6 +1035,29 @@ __global__ void k_tonemap(const float4* __restrict__ acc, uint32_t pixelOffset, 
   for (int k = 0; k < 3; k++) rgb[3 * (size_t)i + k] = tonemapChannel(a.w > 0.0f ? c[k] : 0.0f);
 }
 
+// Pixel[] records (rendering.d:24-30: color, n, sum; 7 floats) from the (sum, n) accumulator, one thread per float so
+// that the 28-byte records are written with dense 4-byte stores.  color = sum / n (rendering.d:483), 0 while n == 0.
+__global__ void k_pack_pixels(const float4* __restrict__ acc, uint32_t pixelOffset, uint32_t count, float* __restrict__ out7) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= count * 7u) return;
+  uint32_t p = j / 7u, c = j - p * 7u;
+  float4 a = acc[pixelOffset + p];
+  uint32_t k = c < 3 ? c : c - 4;                                  // channel (unused for c == 3)
+  float s = k == 0 ? a.x : (k == 1 ? a.y : a.z);
+  float v;
+  if (c < 3) v = a.w > 0.0f ? s / a.w : 0.0f;
+  else if (c == 3) v = a.w;
+  else v = s;
+  out7[j] = v;
+}
+// The inverse for the project file (main.d:227-234): (sum, n) from Pixel[] records.
+__global__ void k_unpack_pixels(const float* __restrict__ in7, uint32_t pixelOffset, uint32_t count, float4* __restrict__ acc) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= count) return;
+  const float* r = in7 + 7 * (size_t)p;
+  acc[pixelOffset + p] = make_float4(r[4], r[5], r[6], r[3]);
+}
+
 // angleToDirection (rendering.d:316-330) as the shading kernels evaluate it; a zero normal selects
 // angleToLocalDirection (rendering.d:309-314).  in5 = (phi, psi, normal) per row.
 __global__ void k_angle_directions(const float* __restrict__ in5, uint32_t n, float* __restrict__ out3) {
@@ -1190,6 +1213,14 @@ void launchHitsNothing(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cf
 
 void launchTonemap(const LaunchCfg& lc, const float4* acc, uint32_t pixelOffset, uint32_t count, uint8_t* rgb) {
   hipLaunchKernelGGL(k_tonemap, dim3((count + 255) / 256), dim3(256), 0, lc.stream, acc, pixelOffset, count, rgb);
+}
+
+void launchPackPixels(const LaunchCfg& lc, const float4* acc, uint32_t pixelOffset, uint32_t count, float* out7) {
+  uint64_t n = (uint64_t)count * 7;
+  hipLaunchKernelGGL(k_pack_pixels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lc.stream, acc, pixelOffset, count, out7);
+}
+void launchUnpackPixels(const LaunchCfg& lc, const float* in7, uint32_t pixelOffset, uint32_t count, float4* acc) {
+  hipLaunchKernelGGL(k_unpack_pixels, dim3((count + 255) / 256), dim3(256), 0, lc.stream, in7, pixelOffset, count, acc);
 }
 
 void launchAngleDirections(const LaunchCfg& lc, const float* in5, uint32_t n, float* out3) {

@@ -298,3 +298,41 @@ def test_lights_and_sky_together_equal_oracle_with_same_streams(require_gpu, fla
         assert np.array_equal(got['sum'].view(np.uint32), ref['sum'].view(np.uint32))
     else:
         assert np.allclose(got['sum'], ref['sum'], rtol=2e-5, atol=1e-7)
+
+
+def test_frame_transfers_pinned_staged_and_overlapped(require_gpu):
+    """Pixel[] read-back / restore and the tone-mapped frame give the same bytes whether the caller's buffer is
+    page-locked (copied into directly) or pageable (through the handle's staging buffer), and whether the tone map is
+    fetched in one call or in two halves with the next pass rendered in between (main.d:273-287's loop shape)."""
+    name, W, H = 'teapot', 200, 120
+    pt = make_tracer(name, W, H, has_sky=1, seed=4); pt.render_frame(3)
+    plain = pt.read_pixels()
+    pinned = pt.host_array(W * H, P.PIXEL_DTYPE)
+    pt._check(pt.lib.ptgpu_read_pixels(pt.h, 0, W * H, pinned.ctypes.data))
+    assert np.array_equal(plain.view(np.uint8), pinned.view(np.uint8))
+    part = pt.read_pixels(1000, 777)
+    assert np.array_equal(part.view(np.uint8), plain[1000:1777].view(np.uint8))
+    rgb = pt.tonemap()
+    a = np.zeros((W * H, 3), np.uint8); b = pt.host_array((W * H, 3), np.uint8)
+    other = make_tracer(name, W, H, has_sky=1, seed=4); other.render_frame(3)
+    for buf in (a, b):                                              # pageable, then page-locked destination
+        pt.tonemap_begin(buf)
+        pt.render_frame(1)                                          # the next pass, queued while the copy is in flight
+        pt.tonemap_end()
+        assert np.array_equal(buf, rgb)                             # the frame as it was when begin was called
+        other.render_frame(1)
+        rgb = pt.tonemap()
+        assert np.array_equal(rgb, other.tonemap())
+    with pytest.raises(P.PtError):
+        pt.tonemap_end()                                            # nothing outstanding
+    pt.tonemap_begin(a)
+    with pytest.raises(P.PtError):
+        pt.tonemap_begin(b)                                         # one at a time
+    pt.tonemap_end()
+    # restore from a page-locked and from a pageable array
+    fresh = make_tracer(name, W, H, has_sky=1, seed=4)
+    fresh.write_pixels(plain); one = fresh.read_pixels()
+    fresh.clear_pixels()
+    fresh._check(fresh.lib.ptgpu_write_pixels(fresh.h, 0, W * H, pinned.ctypes.data)); two = fresh.read_pixels()
+    assert np.array_equal(one.view(np.uint8), plain.view(np.uint8)) and np.array_equal(two.view(np.uint8), plain.view(np.uint8))
+    pt.host_free(pinned); pt.host_free(b)
