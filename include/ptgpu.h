@@ -218,6 +218,43 @@ int ptgpu_bind_accumulator(PtHandle* h, void* devicePtr, uint64_t bytes);
 int ptgpu_get_accumulator(PtHandle* h, void** devicePtr, uint64_t* bytes);
 int ptgpu_set_stream(PtHandle* h, void* hipStream);
 
+/* ---- several GPUs of one node behind one object -------------------------------------------------------------------
+ * The reference spreads a frame over worker threads as one task per 4 scanlines with a barrier per pass
+ * (main.d:184-215, 273-288).  A group does the same over GPUs: the scene is replicated, GPU i of G renders the bands
+ * i, i + G, ... (PT_SPLIT_BANDS: the frame is bit-identical for any G), or every pixel with the sample indices
+ * i, i + G, ... (PT_SPLIT_SAMPLES: G x spp samples per pixel), each on its own host thread; ptgpu_group_combine puts the
+ * frame together on the root GPU with one exchange over RCCL (bands: every GPU sends its rows, 1/G of the frame, to the
+ * root; samples: one reduce(sum) of the (sum, n) accumulators).  The library is opened with dlopen when the first group
+ * is created; one GPU works without it. */
+typedef struct PtGroup PtGroup;
+#define PT_SPLIT_BANDS 0
+#define PT_SPLIT_SAMPLES 1
+/* cfg->device is ignored; devices = HIP ordinals (all -1: a host-only group for scene preparation); root indexes devices. */
+int ptgpu_group_create(const PtConfig* cfg, const int32_t* devices, uint32_t numDevices, uint32_t root, PtGroup** out);
+int ptgpu_group_destroy(PtGroup* g);
+int ptgpu_group_info(PtGroup* g, uint32_t* numDevices, uint32_t* root, uint32_t* usesRccl);
+/* The renderer of one GPU (any ptgpu_* call works on it) and the handle whose Pixel[] is the combined frame: read it
+ * with ptgpu_read_pixels / ptgpu_tonemap* after ptgpu_group_combine. */
+int ptgpu_group_handle(PtGroup* g, uint32_t rank, PtHandle** out);
+int ptgpu_group_frame(PtGroup* g, PtHandle** out);
+/* ptgpu_load_thmodel / ptgpu_upload_scene / ptgpu_set_camera / ptgpu_camera_look_at on every GPU. */
+int ptgpu_group_load_thmodel(PtGroup* g, const char* path, int materialTable, const float* modelMatrix);
+int ptgpu_group_upload_scene(PtGroup* g, const float* v, const float* n, const uint32_t* matIdx, const PtMaterial* mats,
+                             uint32_t numTriangles, uint32_t numMaterials);
+int ptgpu_group_set_camera(PtGroup* g, const float pos[3], const float dir[3], const float right[3], const float up[3],
+                           float tanFov, float aspect);
+int ptgpu_group_camera_look_at(PtGroup* g, float fovDegrees, float aspect, const float from[3], const float to[3],
+                               const float up[3]);
+/* One pass of spp samples per pixel, shared out as above (asynchronous on every GPU).  Each GPU keeps its own Pixel[]
+ * between passes; the split is fixed from the first pass until ptgpu_group_clear. */
+int ptgpu_group_render(PtGroup* g, int split, uint32_t bandRows, uint32_t spp);
+int ptgpu_group_combine(PtGroup* g);
+int ptgpu_group_clear(PtGroup* g);
+/* The scanlines of the bands bandFirst, bandFirst + bandStride, ... (main.d:184-192 with bandRows = 4), in order:
+ * up to cap of them in rows (may be NULL), their number in *count.  Pure host arithmetic. */
+int ptgpu_band_rows(uint32_t height, uint32_t bandRows, uint32_t bandFirst, uint32_t bandStride, uint32_t* rows, uint32_t cap,
+                    uint32_t* count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,23 @@ SYMBOLS = {
     'ptgpu_set_stream': (_I, [_VP, _VP]),
 }
 
+SYMBOLS.update({
+    'ptgpu_group_create': (_I, [C.POINTER(PtConfig), _VP, _U32, _U32, C.POINTER(_VP)]),
+    'ptgpu_group_destroy': (_I, [_VP]),
+    'ptgpu_group_info': (_I, [_VP, _VP, _VP, _VP]),
+    'ptgpu_group_handle': (_I, [_VP, _U32, C.POINTER(_VP)]),
+    'ptgpu_group_frame': (_I, [_VP, C.POINTER(_VP)]),
+    'ptgpu_group_load_thmodel': (_I, [_VP, C.c_char_p, _I, _VP]),
+    'ptgpu_group_upload_scene': (_I, [_VP, _VP, _VP, _VP, _VP, _U32, _U32]),
+    'ptgpu_group_set_camera': (_I, [_VP, _VP, _VP, _VP, _VP, _F, _F]),
+    'ptgpu_group_camera_look_at': (_I, [_VP, _F, _F, _VP, _VP, _VP]),
+    'ptgpu_group_render': (_I, [_VP, _I, _U32, _U32]),
+    'ptgpu_group_combine': (_I, [_VP]),
+    'ptgpu_group_clear': (_I, [_VP]),
+    'ptgpu_band_rows': (_I, [_U32, _U32, _U32, _U32, _VP, _U32, _VP]),
+})
+PT_SPLIT_BANDS, PT_SPLIT_SAMPLES = 0, 1
+
 _lib = None
 
 

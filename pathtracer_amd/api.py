@@ -327,6 +327,95 @@ class PathTracer:
         self._check(self.lib.ptgpu_set_stream(self.h, C.c_void_p(stream_ptr)))
 
 
+class _Borrowed(PathTracer):
+    """A PathTracer view of a handle that a GpuGroup owns (never destroyed from here)."""
+
+    def __init__(self, lib, handle, width, height):
+        self.lib, self.h, self.width, self.height = lib, handle, width, height
+        self.cfg = PtConfig(); self._acc_keepalive = None
+
+    def close(self):
+        self.h = None
+
+
+class GpuGroup:
+    """Several GPUs of one node as one renderer (ptgpu_group_*): main.d:184-215's bands, a GPU per worker thread."""
+
+    def __init__(self, width, height, devices, root=0, **kw):
+        self.lib = _lib.load()
+        proto = PathTracer.__new__(PathTracer)
+        proto.cfg = PtConfig(); proto.cfg.width, proto.cfg.height, proto.cfg.hasLights = width, height, 1
+        proto.cfg.sunDir[:] = [float(x) for x in default_sun_dir()]
+        proto.cfg.sunRadiance[:] = [1.0, 0.984, 0.8]
+        proto.cfg.skyRadiance[:] = [float(x) for x in default_sky_radiance()]
+        proto._apply(kw)
+        proto.h = None
+        devs = np.ascontiguousarray(devices, np.int32)
+        g = C.c_void_p()
+        self._check(self.lib.ptgpu_group_create(C.byref(proto.cfg), _ptr(devs), len(devs), root, C.byref(g)))
+        self.g, self.width, self.height, self.n = g, width, height, len(devs)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise PtError(rc, self.lib.ptgpu_last_error().decode(errors='replace'))
+
+    def close(self):
+        if getattr(self, 'g', None):
+            self.lib.ptgpu_group_destroy(self.g); self.g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        n, root, rccl = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._check(self.lib.ptgpu_group_info(self.g, C.byref(n), C.byref(root), C.byref(rccl)))
+        return {'devices': n.value, 'root': root.value, 'rccl': bool(rccl.value)}
+
+    def rank(self, i):
+        h = C.c_void_p(); self._check(self.lib.ptgpu_group_handle(self.g, i, C.byref(h)))
+        return _Borrowed(self.lib, h, self.width, self.height)
+
+    def frame(self):
+        h = C.c_void_p(); self._check(self.lib.ptgpu_group_frame(self.g, C.byref(h)))
+        return _Borrowed(self.lib, h, self.width, self.height)
+
+    def Scene(self, path, matFunc=FILL_MATERIAL, modelMatrix=None):
+        mm = None if modelMatrix is None else np.ascontiguousarray(modelMatrix, np.float32).reshape(16)
+        self._check(self.lib.ptgpu_group_load_thmodel(self.g, str(path).encode(), int(matFunc), _ptr(mm)))
+        return self
+
+    def set_camera(self, cam):
+        s = np.ascontiguousarray(cam.state if isinstance(cam, Camera) else cam, np.float32)
+        self._check(self.lib.ptgpu_group_set_camera(self.g, _ptr(s[0:3].copy()), _ptr(s[3:6].copy()), _ptr(s[6:9].copy()),
+                                                    _ptr(s[9:12].copy()), float(s[12]), float(s[13])))
+        return self
+
+    def render(self, spp, split='bands', band_rows=4):
+        self._check(self.lib.ptgpu_group_render(self.g, {'bands': 0, 'samples': 1}[split], band_rows, spp))
+
+    def combine(self):
+        self._check(self.lib.ptgpu_group_combine(self.g))
+        return self.frame()
+
+    def clear(self):
+        self._check(self.lib.ptgpu_group_clear(self.g))
+
+
+def band_rows(height, band_rows_, first, stride):
+    """ptgpu_band_rows: the scanlines of bands first, first + stride, ... (main.d:184-192)."""
+    lib = _lib.load()
+    cnt = C.c_uint32()
+    rc = lib.ptgpu_band_rows(height, band_rows_, first, stride, None, 0, C.byref(cnt))
+    if rc:
+        raise PtError(rc, lib.ptgpu_last_error().decode())
+    rows = np.zeros(max(1, cnt.value), np.uint32)
+    lib.ptgpu_band_rows(height, band_rows_, first, stride, _ptr(rows), cnt.value, C.byref(cnt))
+    return rows[:cnt.value]
+
+
 def pixels_from_accumulator(acc):
     """(sum.rgb, n) rows -> Pixel records with color = sum / n (rendering.d:483)."""
     acc = np.asarray(acc, np.float32).reshape(-1, 4)

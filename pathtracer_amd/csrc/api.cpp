@@ -1134,3 +1134,312 @@ int ptgpu_set_stream(PtHandle* h, void* hipStream) {
 }
 
 }  // extern "C"
+
+// ======================================================================================================================
+// Several GPUs behind one object: the reference's task decomposition (one ComputeOutputTask per 4 scanlines pulled by
+// worker threads, a barrier per pass, main.d:184-215, 273-288) with a GPU in the place of a worker thread.  The scene
+// is replicated; GPU i renders bands i, i + G, ... (or, for the sample split, every pixel with its own residue class
+// of sample indices); one exchange over RCCL puts the frame together on one GPU.
+// ======================================================================================================================
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is opened at run time, not linked
+#include <thread>
+
+namespace {
+
+// librccl, opened on first use.  In a process that already holds an RCCL (torch's), the loader hands back that one.
+struct Rccl {
+  void* lib = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclReduce) Reduce = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string why;
+  bool ok() const { return lib != nullptr; }
+};
+Rccl& rccl() {
+  static Rccl r; static std::once_flag once;
+  std::call_once(once, []() {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) { const char* e = dlerror(); r.why = e ? e : "librccl.so not found"; return; }
+    auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p) { r.why = std::string("librccl lacks ") + n; } return p; };
+    r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll"); r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.Reduce = (decltype(r.Reduce))sym("ncclReduce"); r.Send = (decltype(r.Send))sym("ncclSend"); r.Recv = (decltype(r.Recv))sym("ncclRecv");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart"); r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    if (!r.why.empty()) { dlclose(r.lib); r.lib = nullptr; }
+  });
+  return r;
+}
+#define NCCLCHECK(expr)                                                                                          \
+  do {                                                                                                           \
+    ncclResult_t r_ = (expr);                                                                                    \
+    if (r_ != ncclSuccess) fail(PT_E_DEVICE, std::string(#expr) + ": " + rccl().GetErrorString(r_));              \
+  } while (0)
+
+// Rows of the bands first, first + stride, ... of bandRows scanlines in a frame of `height` rows, in order.
+void bandRowsOf(uint32_t height, uint32_t bandRows, uint32_t first, uint32_t stride, std::vector<uint32_t>& rows) {
+  rows.clear();
+  uint32_t numBands = (height + bandRows - 1) / bandRows;
+  for (uint32_t b = first; b < numBands; b += stride)
+    for (uint32_t r = b * bandRows; r < std::min(height, (b + 1) * bandRows); r++) rows.push_back(r);
+}
+uint32_t bandsOfRank(uint32_t height, uint32_t bandRows, uint32_t first, uint32_t stride) {
+  uint32_t numBands = (height + bandRows - 1) / bandRows;
+  return first < numBands ? (numBands - first + stride - 1) / stride : 0;
+}
+
+}  // namespace
+
+struct PtGroup {
+  std::vector<PtHandle*> ranks;       // one renderer per GPU
+  PtHandle* frame = nullptr;          // a handle without a scene on the root GPU: its accumulator is the combined frame
+  uint32_t root = 0;
+  std::vector<ncclComm_t> comms;      // empty when the exchange runs without RCCL (one GPU and no library)
+  std::vector<DevBuf> packed;         // per rank: its band rows, dense (on the rank's GPU)
+  std::vector<DevBuf> recv;           // per rank: the same rows as received on the root GPU
+  // what the last ptgpu_group_render shared out, so that combine knows what to collect
+  int split = -1; uint32_t bandRows = 4;
+  bool hostOnly = false;
+};
+
+namespace {
+
+// Runs f(rank) on one host thread per GPU (the calling thread takes rank 0) and rethrows the first failure.
+template <typename F> void onEveryRank(PtGroup* g, F&& f) {
+  const size_t n = g->ranks.size();
+  std::vector<int> codes(n, PT_OK); std::vector<std::string> msgs(n);
+  auto run = [&](size_t r) {
+    try { f((uint32_t)r); }
+    catch (const ApiError& e) { codes[r] = e.code; msgs[r] = e.msg; }
+    catch (const IoError& e) { codes[r] = PT_E_IO; msgs[r] = e.what(); }
+    catch (const std::exception& e) { codes[r] = PT_E_INVALID; msgs[r] = e.what(); }
+  };
+  std::vector<std::thread> th;
+  for (size_t r = 1; r < n; r++) th.emplace_back(run, r);
+  run(0);
+  for (auto& t : th) t.join();
+  for (size_t r = 0; r < n; r++) if (codes[r] != PT_OK) fail(codes[r], "GPU " + std::to_string(r) + ": " + msgs[r]);
+}
+void must(int rc) { if (rc != PT_OK) fail(rc, ptgpu_last_error()); }
+
+}  // namespace
+
+extern "C" {
+
+int ptgpu_band_rows(uint32_t height, uint32_t bandRows, uint32_t bandFirst, uint32_t bandStride, uint32_t* rows, uint32_t cap,
+                    uint32_t* count) {
+  return guarded([&]() {
+    if (!count) fail(PT_E_INVALID, "null argument");
+    if (bandRows == 0 || bandStride == 0 || bandFirst >= bandStride) fail(PT_E_INVALID, "need bandRows > 0 and bandFirst < bandStride");
+    std::vector<uint32_t> r; bandRowsOf(height, bandRows, bandFirst, bandStride, r);
+    *count = (uint32_t)r.size();
+    if (rows) for (uint32_t i = 0; i < r.size() && i < cap; i++) rows[i] = r[i];
+  });
+}
+
+int ptgpu_group_create(const PtConfig* cfg, const int32_t* devices, uint32_t numDevices, uint32_t root, PtGroup** out) {
+  if (out) *out = nullptr;
+  PtGroup* g = nullptr;
+  int rc = guarded([&]() {
+    if (!cfg || !devices || !out || numDevices == 0) fail(PT_E_INVALID, "null argument or no device");
+    if (root >= numDevices) fail(PT_E_INVALID, "root must be one of the devices");
+    g = new PtGroup(); g->root = root;
+    g->packed.resize(numDevices); g->recv.resize(numDevices);
+    g->hostOnly = devices[0] < 0;
+    for (uint32_t i = 0; i < numDevices; i++) {
+      if ((devices[i] < 0) != g->hostOnly) fail(PT_E_INVALID, "host-only (-1) and real devices cannot be mixed");
+      for (uint32_t j = 0; j < i; j++) if (!g->hostOnly && devices[j] == devices[i]) fail(PT_E_INVALID, "device listed twice");
+      PtConfig c = *cfg; c.device = devices[i];
+      PtHandle* h = nullptr; must(ptgpu_create(&c, &h));
+      g->ranks.push_back(h);
+    }
+    { PtConfig c = *cfg; c.device = devices[root]; must(ptgpu_create(&c, &g->frame)); }
+    if (!g->hostOnly) {
+      Rccl& r = rccl();
+      if (r.ok()) {
+        g->comms.resize(numDevices);
+        std::vector<int> devs(devices, devices + numDevices);
+        NCCLCHECK(r.CommInitAll(g->comms.data(), (int)numDevices, devs.data()));
+      } else if (numDevices > 1) {
+        fail(PT_E_DEVICE, "more than one GPU needs RCCL, which could not be opened: " + r.why);
+      }
+    }
+  });
+  if (rc != PT_OK) { if (g) ptgpu_group_destroy(g); return rc; }
+  *out = g; return PT_OK;
+}
+
+int ptgpu_group_destroy(PtGroup* g) {
+  if (!g) return PT_OK;
+  return guarded([&]() {
+    for (PtHandle* h : g->ranks) if (h && h->cfg.device >= 0) { (void)hipSetDevice(h->cfg.device); (void)hipStreamSynchronize(h->stream); }
+    for (ncclComm_t c : g->comms) if (c) (void)rccl().CommDestroy(c);
+    for (size_t r = 0; r < g->ranks.size(); r++) {
+      if (g->ranks[r] && g->ranks[r]->cfg.device >= 0) (void)hipSetDevice(g->ranks[r]->cfg.device);
+      g->packed[r].release();
+    }
+    if (g->frame && g->frame->cfg.device >= 0) (void)hipSetDevice(g->frame->cfg.device);
+    for (DevBuf& b : g->recv) b.release();
+    for (PtHandle* h : g->ranks) (void)ptgpu_destroy(h);
+    (void)ptgpu_destroy(g->frame);
+    delete g;
+  });
+}
+
+int ptgpu_group_info(PtGroup* g, uint32_t* numDevices, uint32_t* root, uint32_t* usesRccl) {
+  return guarded([&]() {
+    if (!g) fail(PT_E_INVALID, "null group");
+    if (numDevices) *numDevices = (uint32_t)g->ranks.size();
+    if (root) *root = g->root;
+    if (usesRccl) *usesRccl = g->comms.empty() ? 0u : 1u;
+  });
+}
+
+int ptgpu_group_handle(PtGroup* g, uint32_t rank, PtHandle** out) {
+  return guarded([&]() {
+    if (!g || !out) fail(PT_E_INVALID, "null argument");
+    if (rank >= g->ranks.size()) fail(PT_E_INVALID, "rank out of range");
+    *out = g->ranks[rank];
+  });
+}
+
+int ptgpu_group_frame(PtGroup* g, PtHandle** out) {
+  return guarded([&]() {
+    if (!g || !out) fail(PT_E_INVALID, "null argument");
+    *out = g->frame;
+  });
+}
+
+int ptgpu_group_load_thmodel(PtGroup* g, const char* path, int materialTable, const float* modelMatrix) {
+  return guarded([&]() {
+    if (!g || !path) fail(PT_E_INVALID, "null argument");
+    onEveryRank(g, [&](uint32_t r) { must(ptgpu_load_thmodel(g->ranks[r], path, materialTable, modelMatrix)); });
+  });
+}
+
+int ptgpu_group_upload_scene(PtGroup* g, const float* v, const float* n, const uint32_t* matIdx, const PtMaterial* mats,
+                             uint32_t numTriangles, uint32_t numMaterials) {
+  return guarded([&]() {
+    if (!g) fail(PT_E_INVALID, "null group");
+    onEveryRank(g, [&](uint32_t r) { must(ptgpu_upload_scene(g->ranks[r], v, n, matIdx, mats, numTriangles, numMaterials)); });
+  });
+}
+
+int ptgpu_group_set_camera(PtGroup* g, const float pos[3], const float dir[3], const float right[3], const float up[3], float tanFov,
+                           float aspect) {
+  return guarded([&]() {
+    if (!g) fail(PT_E_INVALID, "null group");
+    for (PtHandle* h : g->ranks) must(ptgpu_set_camera(h, pos, dir, right, up, tanFov, aspect));
+  });
+}
+
+int ptgpu_group_camera_look_at(PtGroup* g, float fovDegrees, float aspect, const float from[3], const float to[3], const float up[3]) {
+  return guarded([&]() {
+    if (!g) fail(PT_E_INVALID, "null group");
+    for (PtHandle* h : g->ranks) must(ptgpu_camera_look_at(h, fovDegrees, aspect, from, to, up, nullptr));
+  });
+}
+
+int ptgpu_group_render(PtGroup* g, int split, uint32_t bandRows, uint32_t spp) {
+  return guarded([&]() {
+    if (!g) fail(PT_E_INVALID, "null group");
+    if (split != PT_SPLIT_BANDS && split != PT_SPLIT_SAMPLES) fail(PT_E_INVALID, "split must be PT_SPLIT_BANDS or PT_SPLIT_SAMPLES");
+    if (split == PT_SPLIT_BANDS && bandRows == 0) fail(PT_E_INVALID, "bandRows must be > 0");
+    if (g->split >= 0 && g->split != split) fail(PT_E_STATE, "the split of a group is fixed by its first ptgpu_group_render (clear with ptgpu_group_clear)");
+    if (g->split == PT_SPLIT_BANDS && g->bandRows != bandRows) fail(PT_E_STATE, "bandRows changed between passes");
+    const uint32_t G = (uint32_t)g->ranks.size();
+    onEveryRank(g, [&](uint32_t r) {
+      PtHandle* h = g->ranks[r];
+      if (split == PT_SPLIT_BANDS) must(ptgpu_render_bands(h, bandRows, r, G, spp));
+      else {
+        PtConfig c = h->cfg; c.sampleBase = r; c.sampleStride = G;
+        must(ptgpu_set_config(h, &c));
+        must(ptgpu_render(h, 0, h->cfg.width * h->cfg.height, spp));
+      }
+    });
+    g->split = split; g->bandRows = bandRows;
+  });
+}
+
+int ptgpu_group_clear(PtGroup* g) {
+  return guarded([&]() {
+    if (!g) fail(PT_E_INVALID, "null group");
+    for (PtHandle* h : g->ranks) must(ptgpu_clear_pixels(h));
+    must(ptgpu_clear_pixels(g->frame));
+    g->split = -1;
+  });
+}
+
+int ptgpu_group_combine(PtGroup* g) {
+  return guarded([&]() {
+    if (!g) fail(PT_E_INVALID, "null group");
+    if (g->hostOnly) fail(PT_E_DEVICE, "this group was created without devices");
+    if (g->split < 0) fail(PT_E_STATE, "nothing rendered yet");
+    const uint32_t G = (uint32_t)g->ranks.size(), root = g->root;
+    PtHandle* F = g->frame;
+    const uint32_t W = F->cfg.width, H = F->cfg.height;
+    const size_t frameFloats = (size_t)W * H * 4;
+    const bool useRccl = !g->comms.empty();
+    Rccl& R = rccl();
+    if (g->split == PT_SPLIT_SAMPLES) {
+      // every rank holds (sum, n) of all pixels for its own samples: one reduce(sum) onto the root's frame buffer
+      if (useRccl) {
+        NCCLCHECK(R.GroupStart());
+        for (uint32_t r = 0; r < G; r++) {
+          PtHandle* h = g->ranks[r];
+          HIPCHECK(hipSetDevice(h->cfg.device));
+          NCCLCHECK(R.Reduce(h->acc, r == root ? (void*)F->acc : nullptr, frameFloats, ncclFloat, ncclSum, (int)root, g->comms[r], h->stream));
+        }
+        NCCLCHECK(R.GroupEnd());
+      } else {
+        HIPCHECK(hipSetDevice(F->cfg.device));
+        HIPCHECK(hipMemcpyAsync(F->acc, g->ranks[0]->acc, frameFloats * 4, hipMemcpyDeviceToDevice, g->ranks[0]->stream));
+      }
+    } else {
+      // disjoint rows: every rank packs its bands into a dense buffer, the others send theirs to the root (1/G of the
+      // frame each instead of a reduce over G whole frames), the root scatters all of them into the frame buffer
+      std::vector<uint32_t> packedRows(G);
+      for (uint32_t r = 0; r < G; r++) {
+        PtHandle* h = g->ranks[r];
+        packedRows[r] = bandsOfRank(H, g->bandRows, r, G) * g->bandRows;
+        HIPCHECK(hipSetDevice(h->cfg.device));
+        g->packed[r].alloc((size_t)packedRows[r] * W * 16);
+        LaunchCfg lc = makeLaunchCfg(h);
+        launchBandRows(lc, h->acc, g->packed[r].as<float4>(), W, H, g->bandRows, r, G, packedRows[r], false);
+        HIPCHECK(hipGetLastError());
+      }
+      HIPCHECK(hipSetDevice(F->cfg.device));
+      for (uint32_t r = 0; r < G; r++) if (r != root) g->recv[r].alloc((size_t)packedRows[r] * W * 16);
+      PtHandle* hr = g->ranks[root];
+      if (G > 1) {
+        NCCLCHECK(R.GroupStart());
+        for (uint32_t r = 0; r < G; r++) {
+          if (r == root || !packedRows[r]) continue;
+          const size_t cnt = (size_t)packedRows[r] * W * 4;
+          HIPCHECK(hipSetDevice(g->ranks[r]->cfg.device));
+          NCCLCHECK(R.Send(g->packed[r].p, cnt, ncclFloat, (int)root, g->comms[r], g->ranks[r]->stream));
+          HIPCHECK(hipSetDevice(hr->cfg.device));
+          NCCLCHECK(R.Recv(g->recv[r].p, cnt, ncclFloat, (int)r, g->comms[root], hr->stream));
+        }
+        NCCLCHECK(R.GroupEnd());
+      }
+      HIPCHECK(hipSetDevice(hr->cfg.device));
+      LaunchCfg lc = makeLaunchCfg(hr);                    // on the root rank's stream, behind its receives
+      for (uint32_t r = 0; r < G; r++)
+        launchBandRows(lc, F->acc, r == root ? g->packed[r].as<float4>() : g->recv[r].as<float4>(), W, H, g->bandRows, r, G, packedRows[r], true);
+      HIPCHECK(hipGetLastError());
+    }
+    for (PtHandle* h : g->ranks) { HIPCHECK(hipSetDevice(h->cfg.device)); HIPCHECK(hipStreamSynchronize(h->stream)); }
+    HIPCHECK(hipSetDevice(F->cfg.device));
+  });
+}
+
+}  // extern "C"

@@ -202,6 +202,8 @@ void launchHitsNothing(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cf
 void launchTonemap(const LaunchCfg& lc, const float4* acc, uint32_t pixelOffset, uint32_t count, uint8_t* rgb);
 void launchPackPixels(const LaunchCfg& lc, const float4* acc, uint32_t pixelOffset, uint32_t count, float* out7);
 void launchUnpackPixels(const LaunchCfg& lc, const float* in7, uint32_t pixelOffset, uint32_t count, float4* acc);
+void launchBandRows(const LaunchCfg& lc, float4* frame, float4* packed, uint32_t W, uint32_t H, uint32_t bandRows, uint32_t first,
+                    uint32_t stride, uint32_t packedRows, bool unpack);
 void launchAngleDirections(const LaunchCfg& lc, const float* in5, uint32_t n, float* out3);
 // Writes n queue descriptors over the counter words at `words` (PT_QMETA_WORDS each), as the host lays them out.
 void launchInitMetas(const LaunchCfg& lc, QMeta* desc, uint32_t* words, uint32_t n);

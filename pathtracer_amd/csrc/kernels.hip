@@ -1223,6 +1223,27 @@ void launchUnpackPixels(const LaunchCfg& lc, const float* in7, uint32_t pixelOff
   hipLaunchKernelGGL(k_unpack_pixels, dim3((count + 255) / 256), dim3(256), 0, lc.stream, in7, pixelOffset, count, acc);
 }
 
+// The rows of a rank's bands (bands first, first + stride, ... of bandRows scanlines) as one dense buffer, for the
+// exchange between GPUs: pack copies them out of a full-frame accumulator, unpack copies them into one.
+__global__ void k_band_rows(float4* __restrict__ frame, float4* __restrict__ packed, uint32_t W, uint32_t H, uint32_t bandRows,
+                            uint32_t first, uint32_t stride, uint32_t packedRows, int unpack) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= packedRows * W) return;
+  uint32_t pr = i / W, col = i - pr * W;
+  uint32_t j = pr / bandRows, r = pr - j * bandRows;                   // j-th band of the rank, row r inside it
+  uint32_t row = (first + j * stride) * bandRows + r;
+  if (row >= H) return;
+  size_t f = (size_t)row * W + col;
+  if (unpack) frame[f] = packed[i]; else packed[i] = frame[f];
+}
+void launchBandRows(const LaunchCfg& lc, float4* frame, float4* packed, uint32_t W, uint32_t H, uint32_t bandRows, uint32_t first,
+                    uint32_t stride, uint32_t packedRows, bool unpack) {
+  uint64_t n = (uint64_t)packedRows * W;
+  if (!n) return;
+  hipLaunchKernelGGL(k_band_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lc.stream, frame, packed, W, H, bandRows, first,
+                     stride, packedRows, unpack ? 1 : 0);
+}
+
 void launchAngleDirections(const LaunchCfg& lc, const float* in5, uint32_t n, float* out3) {
   hipLaunchKernelGGL(k_angle_directions, dim3((n + 255) / 256), dim3(256), 0, lc.stream, in5, n, out3);
 }

@@ -336,3 +336,33 @@ def test_frame_transfers_pinned_staged_and_overlapped(require_gpu):
     fresh._check(fresh.lib.ptgpu_write_pixels(fresh.h, 0, W * H, pinned.ctypes.data)); two = fresh.read_pixels()
     assert np.array_equal(one.view(np.uint8), plain.view(np.uint8)) and np.array_equal(two.view(np.uint8), plain.view(np.uint8))
     pt.host_free(pinned); pt.host_free(b)
+
+
+@pytest.mark.parametrize('split', ['bands', 'samples'])
+def test_native_group_of_one_gpu_equals_a_single_handle(require_gpu, split):
+    """ptgpu_group_* with one GPU (all a one-GPU box can hold): share-out, two passes, the exchange (RCCL with a
+    communicator of one rank) and the combined frame, which equals a plain handle's render bit for bit."""
+    name, W, H, spp = 'teapot', 160, 90, 3
+    g = P.GpuGroup(W, H, [0], has_sky=1, seed=21)
+    assert g.info() == {'devices': 1, 'root': 0, 'rccl': True}
+    g.Scene(conftest_model(name))
+    cam = P.Camera(30.0, H / W).setTransform(CAMERAS[name][0], CAMERAS[name][1], (0, 0, 1))
+    g.set_camera(cam)
+    g.render(spp, split=split); g.render(2, split=split)
+    frame = g.combine()
+    got = frame.read_pixels()
+    one = make_tracer(name, W, H, has_sky=1, seed=21); one.render_frame(spp + 2)
+    want = one.read_pixels()
+    assert np.array_equal(got['n'], want['n']) and np.array_equal(got['sum'].view(np.uint32), want['sum'].view(np.uint32))
+    assert np.array_equal(frame.tonemap(), one.tonemap())
+    with pytest.raises(P.PtError):
+        g.render(1, split='samples' if split == 'bands' else 'bands')      # the split is fixed until clear
+    g.clear()
+    g.render(1, split='samples' if split == 'bands' else 'bands')
+    assert (g.combine().read_pixels()['n'] == 1).all()
+    g.close()
+
+
+def conftest_model(name):
+    from conftest import model_path
+    return model_path(name)

@@ -129,3 +129,34 @@ def test_sample_split_draws_disjoint_indices_over_several_passes():
         assert len(t.drawn) == passes * SPP and all(i % world == rank for i in t.drawn)
         drawn += t.drawn
     assert sorted(drawn) == list(range(passes * world * SPP))
+
+
+def test_native_band_bookkeeping_and_host_only_group():
+    """ptgpu_band_rows (the rows GPU i of G renders and sends) against the Python share-out, and a group without
+    devices: scene and camera reach every rank, rendering fails loudly."""
+    import pathtracer_amd as P
+    from conftest import model_path
+    for height, rows, world in ((23, 4, 2), (1080, 4, 8), (240, 4, 3), (7, 16, 4), (64, 1, 5)):
+        seen = []
+        for rank in range(world):
+            got = P.band_rows(height, rows, rank, world)
+            assert list(got) == multigpu.rows_of_rank(height, rows, rank, world)
+            seen += list(got)
+        assert sorted(seen) == list(range(height))                      # every scanline exactly once
+    with pytest.raises(P.PtError):
+        P.band_rows(10, 4, 2, 2)
+    g = P.GpuGroup(32, 24, [-1, -1, -1], root=1)
+    assert g.info() == {'devices': 3, 'root': 1, 'rccl': False}
+    g.Scene(model_path('cornell-box'))
+    g.set_camera(P.Camera(30.0, 24 / 32).setTransform((-1, 26.5, 10), (0, 0, 9), (0, 0, 1)))
+    for r in range(3):
+        st = g.rank(r).stats()
+        assert st.numTriangles == 52 and st.numLightGroups == 1
+    with pytest.raises(P.PtError) as e:
+        g.render(1)
+    assert e.value.code == -3 and 'GPU 0' in str(e.value)
+    with pytest.raises(P.PtError):
+        g.combine()
+    with pytest.raises(P.PtError):
+        P.GpuGroup(32, 24, [-1, 0])
+    g.close()
