@@ -86,6 +86,8 @@ typedef struct PtStats {
   uint64_t nodesAny, trisAny;           /* same for any-hit rays                                          */
   uint64_t raysCulled;       /* view rays answered without a traversal: pixel outside every triangle's screen
                                 rectangle, or ray outside the scene's bounding box (included in raysPrimary)  */
+  uint64_t hits;             /* Scene.trace calls of computeL / computeLindirect that hit: vertices shaded     */
+  uint64_t envEntries;       /* shaded vertices that trace a sun ray, a sky ray or both (one queue entry each) */
   double kernelMs[PT_K_COUNT];          /* with PT_FLAG_TIME_KERNELS: summed event time per kernel kind   */
   uint64_t kernelLaunches[PT_K_COUNT];
   double renderMs;           /* event time first kernel -> last kernel of all ptgpu_render calls          */
@@ -93,6 +95,8 @@ typedef struct PtStats {
   uint32_t sceneInLds;       /* 1 if nodes + triangles are staged in LDS by the traversal kernels         */
   uint32_t bvhOnGpu;         /* 1 if the BVH of the current scene was built on the GPU                    */
   double bvhBuildSeconds;    /* wall time of that build (host or GPU, transfers included)                 */
+  double maskBuildMs;        /* host time of the last build + upload of the view-ray masks (done inside the first
+                                ptgpu_render after the scene or the camera changed)                         */
 } PtStats;
 
 const char* ptgpu_last_error(void);

@@ -25,10 +25,11 @@ class PtStats(C.Structure):
     _fields_ = [('raysPrimary', C.c_uint64), ('raysLight', C.c_uint64), ('raysIndirect', C.c_uint64),
                 ('raysOcclusion', C.c_uint64), ('samples', C.c_uint64), ('nodesClosest', C.c_uint64),
                 ('trisClosest', C.c_uint64), ('nodesAny', C.c_uint64), ('trisAny', C.c_uint64), ('raysCulled', C.c_uint64),
+                ('hits', C.c_uint64), ('envEntries', C.c_uint64),
                 ('kernelMs', C.c_double * 6), ('kernelLaunches', C.c_uint64 * 6), ('renderMs', C.c_double),
                 ('numTriangles', C.c_uint32), ('numNodes', C.c_uint32), ('bvhDepth', C.c_uint32),
                 ('numLightGroups', C.c_uint32), ('sceneInLds', C.c_uint32), ('bvhOnGpu', C.c_uint32),
-                ('bvhBuildSeconds', C.c_double)]
+                ('bvhBuildSeconds', C.c_double), ('maskBuildMs', C.c_double)]
 
 
 # every symbol include/ptgpu.h declares: name -> (restype, argtypes)

@@ -6,6 +6,7 @@
 #include "thmodel.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -464,6 +465,7 @@ void renderPixels(PtHandle* h, PixMap base, uint64_t totalPix, uint32_t spp, con
   if (totalPix == 0 || spp == 0) return;
   if (!external) ensureWavefront(h);
   if (!external && h->maskDirty) {
+    const auto tMask = std::chrono::steady_clock::now();
     std::vector<uint32_t> bits, sky;
     h->maskUsable = !(h->cfg.flags & PT_FLAG_NO_COVERAGE_MASK) &&
                     buildCoverageMask(h->flat, h->cam, h->cfg.width, h->cfg.height, bits, sky);
@@ -474,6 +476,7 @@ void renderPixels(PtHandle* h, PixMap base, uint64_t totalPix, uint32_t spp, con
       HIPCHECK(hipMemcpy(h->dSkyMask.p, sky.data(), sky.size() * 4, hipMemcpyHostToDevice));
     }
     h->maskDirty = false;
+    h->st.maskBuildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tMask).count();
   }
   DevCfg dc = makeDevCfg(h); LaunchCfg lc = makeLaunchCfg(h);
   lc.maxGroups = maxGroups;
@@ -1084,6 +1087,7 @@ int ptgpu_get_stats(PtHandle* h, PtStats* out) {
     h->st.raysLight = s[STAT_RAYS_LIGHT]; h->st.raysIndirect = s[STAT_RAYS_INDIRECT]; h->st.raysOcclusion = s[STAT_RAYS_OCCL];
     h->st.nodesClosest = s[STAT_NODES_CLOSEST]; h->st.trisClosest = s[STAT_TRIS_CLOSEST];
     h->st.nodesAny = s[STAT_NODES_ANY]; h->st.trisAny = s[STAT_TRIS_ANY]; h->st.raysCulled = s[STAT_RAYS_CULLED];
+    h->st.hits = s[STAT_HITS]; h->st.envEntries = s[STAT_ENV_ENTRIES];
     *out = h->st;
   });
 }
@@ -1098,7 +1102,7 @@ int ptgpu_reset_stats(PtHandle* h) {
     PtStats keep = h->st; h->st = PtStats();
     h->st.numTriangles = keep.numTriangles; h->st.numNodes = keep.numNodes; h->st.bvhDepth = keep.bvhDepth;
     h->st.numLightGroups = keep.numLightGroups; h->st.sceneInLds = keep.sceneInLds;
-    h->st.bvhOnGpu = keep.bvhOnGpu; h->st.bvhBuildSeconds = keep.bvhBuildSeconds;
+    h->st.bvhOnGpu = keep.bvhOnGpu; h->st.bvhBuildSeconds = keep.bvhBuildSeconds; h->st.maskBuildMs = keep.maskBuildMs;
     h->eventOverflow = false;
   });
 }

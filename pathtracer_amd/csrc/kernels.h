@@ -148,7 +148,7 @@ struct Wavefront {
 };
 
 enum { STAT_RAYS_LIGHT = 0, STAT_RAYS_INDIRECT, STAT_RAYS_OCCL, STAT_NODES_CLOSEST, STAT_TRIS_CLOSEST,
-       STAT_NODES_ANY, STAT_TRIS_ANY, STAT_RAYS_CULLED, STAT_COUNT };
+       STAT_NODES_ANY, STAT_TRIS_ANY, STAT_RAYS_CULLED, STAT_HITS, STAT_ENV_ENTRIES, STAT_COUNT };
 
 // Workgroups of a traversal kernel per CU when the scene copy in LDS takes `bytes` (0: it does not fit at all).
 inline uint32_t ldsWorkgroupsPerCU(uint64_t bytes) {

@@ -704,6 +704,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_occluded(DevScene sc, float eps, V3 sunRad
   __syncthreads();
   uint32_t cN = 0, cT = 0, nRays = 0;
   const uint32_t total = q.prefix[PT_SEGS];
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[STAT_ENV_ENTRIES], (unsigned long long)total);
   SegCursor cur; cur.seg = 0; cur.lo = 1; cur.hi = 0;      // empty: the first entry searches
   Chunk ck;
   while (nextChunk(&pool, taskCounter, q, total, 0, ck)) {
@@ -862,6 +863,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg 
   const bool direct = envDirect(cfg, sc, PRIMARY);
   Task tk = taskOf(wf.hitQ, T);
   SegCursor seg = segCursor(wf.hitQ, tk.seg);
+  if (T == 0 && threadIdx.x == 0) atomicAdd(&wf.stats[STAT_HITS], (unsigned long long)wf.hitQ.prefix[PT_SEGS]);
   for (uint32_t base = tk.begin; base < tk.end; base += blockDim.x) {
     uint32_t j = base + threadIdx.x;
     bool active = j < tk.end;

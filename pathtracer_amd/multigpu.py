@@ -63,3 +63,28 @@ def combine(acc, dist=None, dst=0, all_ranks=False):
     else:
         dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM)
     return acc
+
+
+def gather_bands(acc, width, height, band_rows, rank, world, dist, dst=0, via_host=False):
+    """Band split: every rank's accumulator holds its own scanlines and zeros elsewhere.  Instead of reducing `world`
+    whole frames, each rank sends only its rows (1 / world of the frame) to `dst`, which writes them into its own
+    accumulator.  One gather; padded to the largest share so that all pieces have one size.  via_host: move the pieces
+    through host memory (gloo rehearsal)."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return acc
+    frame = acc.view(height, width * 4)
+    shares = [rows_of_rank(height, band_rows, r, world) for r in range(world)]
+    most = max(len(s) for s in shares)
+    dev = 'cpu' if via_host else acc.device
+    mine = torch.tensor(shares[rank], dtype=torch.long, device=acc.device)
+    piece = torch.zeros(most, width * 4, dtype=acc.dtype, device=dev)
+    piece[:len(shares[rank])] = frame.index_select(0, mine).to(dev)
+    pieces = [torch.empty_like(piece) for _ in range(world)] if rank == dst else None
+    dist.gather(piece, pieces, dst=dst)
+    if rank == dst:
+        for r in range(world):
+            if r != dst and shares[r]:
+                idx = torch.tensor(shares[r], dtype=torch.long, device=acc.device)
+                frame.index_copy_(0, idx, pieces[r][:len(shares[r])].to(acc.device))
+    return acc

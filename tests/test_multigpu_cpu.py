@@ -69,7 +69,10 @@ def worker(rank, world, port, split, q):
         acc = torch.zeros(W * H * 4)
         multigpu.render_share(FakeTracer(acc), SPP, rank, world, split=split, band_rows=BAND_ROWS)
         own = acc.clone()
-        multigpu.combine(acc, dist, dst=0)
+        if split == 'bands':                        # disjoint rows: gathered; the sample split is reduced
+            multigpu.gather_bands(acc, W, H, BAND_ROWS, rank, world, dist, dst=0)
+        else:
+            multigpu.combine(acc, dist, dst=0)
         if rank == 0:
             q.put((split, acc.numpy().copy(), own.numpy().copy()))
         both = own.clone()
