@@ -111,9 +111,9 @@ def ceilings(kind, st, visits, ms, launches, pmc, scene_in_lds):
         stream, nodes, tris = rays * B_STREAM_ANY, rays * visits['nodes_any'], rays * visits['tris_any']
     elif kind == 'shade':
         # per shaded vertex: hit record 32 B + three normals 48 B + material 16 B read; written: 48 B per light-group ray,
-        # 64 B per sun/sky entry, 32 + 24 B per continuation ray (ray, throughput + generator state)
+        # 64 B per sun/sky entry, 32 B per continuation ray (+ 24 B of throughput and generator state from the second bounce on: not counted)
         rays = st.hits
-        stream = st.hits * 96.0 + st.raysLight * 48.0 + st.envEntries * 64.0 + st.raysIndirect * 56.0
+        stream = st.hits * 96.0 + st.raysLight * 48.0 + st.envEntries * 64.0 + st.raysIndirect * 32.0
         nodes = tris = 0.0
     else:
         return None

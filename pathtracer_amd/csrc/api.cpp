@@ -6,6 +6,7 @@
 #include "thmodel.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <mutex>
@@ -361,6 +362,8 @@ void ensureWavefront(PtHandle* h) {
   h->bHitA.alloc(capHit * 16); h->bHitB.alloc(capHit * 16);
   h->bRayO.alloc(NI ? capQueue * 16 : 16); h->bRayD.alloc(NI ? capQueue * 16 : 16);      // indirect rays only
   h->bLacc.alloc((uint64_t)lanes * capSlots * 16);
+  // chain records are recognised by the tag of the batch that wrote them: fresh memory must not hold one by chance
+  HIPCHECK(hipMemset(h->bLacc.p, 0, (uint64_t)lanes * capSlots * 16));
   h->bThr.alloc(NI ? (uint64_t)lanes * capSlots * 16 : 16);
   h->bRng.alloc(NI ? (uint64_t)lanes * capSlots * 8 : 16);
   h->bShO.alloc((uint64_t)kinds * capQueue * 16);
@@ -406,8 +409,13 @@ void launchShadowKinds(PtHandle* h, const LaunchCfg& lc, const DevCfg& dc, const
 // Where a batch keeps its state: the handle's own buffers (ensureWavefront) or the static scratch array.
 struct WfState { Wavefront wf; const QMeta* hostMetas; const QMeta* devMetas; ViewMasks masks; };
 
+// Tags of the batches of this process (Wavefront::tag): never zero, never repeated while a record could still hold one.
+std::atomic<uint32_t> g_batchTag{0};
+
 void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, const WfState& ws) {
   Wavefront wf = ws.wf;
+  do { wf.tag = ++g_batchTag; } while (wf.tag == 0);
+  wf.divCap = makeFastDiv(wf.capSlots); wf.round = 0;
   const uint32_t perStage = 2 + PT_MAX_KINDS;
   const int kinds = (int)((dc.hasLights ? h->dsc.numLightGroups : 0) + (dc.hasSky ? 1 : 0));
   const QMeta* desc = ws.devMetas;
@@ -425,6 +433,7 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
   };
   auto stage = [&](uint32_t s, bool primary) {
     bind(s);
+    wf.round = primary ? 0u : s - 2u;
     { Timed t(h, PT_K_EXTEND); launchExtend(lc, h->dsc, dc, pm, h->acc, wf, primary); t.done(); }
     scan((size_t)s * perStage, 1);
     { Timed t(h, PT_K_SHADE); launchShade(lc, h->dsc, dc, pm, h->acc, wf, primary); t.done(); }
@@ -760,6 +769,10 @@ int ptgpu_render_noalloc(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount,
     ws.masks = (!h->maskDirty && h->maskUsable) ? h->masks() : ViewMasks{nullptr, nullptr};
     // the array keeps the last call's contents (of this or any other handle on the device): counters start at zero
     HIPCHECK(hipMemsetAsync(words, 0, nMetas * PT_QMETA_WORDS * 4 + PT_TASK_COUNTERS * 4, h->stream));
+    // ... and so do the chain lanes' radiance records: whatever another call's layout left there must not be taken
+    // for a record of this batch
+    if (L.lanes > 1)
+      HIPCHECK(hipMemsetAsync(base + L.Lacc + (size_t)L.capSlots * 16, 0, (size_t)(L.lanes - 1) * L.capSlots * 16, h->stream));
     LaunchCfg lc = makeLaunchCfg(h);
     launchInitMetas(lc, (QMeta*)(base + L.desc), words, (uint32_t)nMetas);
     HIPCHECK(hipGetLastError());

@@ -145,6 +145,12 @@ struct Wavefront {
   uint32_t capQueue;          // entries per ray / shadow queue (capSlots * max(1, numIndirect) in mode 1)
   uint32_t capHit;            // entries of the hit queue: capQueue + PT_SEGS * PT_HIT_SLACK
   uint32_t lanes;             // 1 + numIndirect in mode 1, else 1
+  uint32_t tag;               // non-zero, different for every batch ever rendered by this process: the w of a chain
+                              // lane's radiance record (lane slots from capSlots up) holds the tag of the batch that
+                              // last wrote it, and a record with another tag reads as zero -- so nobody has to clear
+                              // the five chain records of every shaded view-ray hit (most are never added to)
+  FastDiv divCap;             // division by capSlots
+  uint32_t round;             // bounce round of the stage being launched (0 = hits of the rays the view-ray hits spawned)
 };
 
 enum { STAT_RAYS_LIGHT = 0, STAT_RAYS_INDIRECT, STAT_RAYS_OCCL, STAT_NODES_CLOSEST, STAT_TRIS_CLOSEST,
@@ -184,6 +190,12 @@ void launchExtend(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, co
 void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
                  const Wavefront& wf, bool primary);
 void launchConnect(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, float area);
+// Radiance record of lane slot `slot` as the adding kernels read it: a chain lane written by an earlier batch is zero.
+__device__ __forceinline__ float4 loadLacc(const float4* Lacc, uint32_t slot, uint32_t capSlots, uint32_t tag) {
+  float4 L = Lacc[slot];
+  if (slot >= capSlots && __float_as_uint(L.w) != tag) L = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(tag));
+  return L;
+}
 // primary: the queue was filled by the shading of view-ray hits
 void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, bool primary);
 void launchAccumulate(const LaunchCfg& lc, const ViewMasks& masks, const DevCfg& cfg, const PixMap& pm, float4* acc,

@@ -561,6 +561,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend(DevScene sc, DevCfg cfg, PixMap pm,
     uint32_t j = ck.begin + (threadIdx.x & 63u);
     bool isHit = false;
     V3 hitPos = v3(0, 0, 0); Hit h; h.t = 0; h.u = 0; h.v = 0; h.tri = 0; uint32_t slot = 0;
+    float carry = 0.0f;                       // fourth word of an indirect ray's direction record, handed on to shade
     if (j < ck.end) {
       uint32_t e = physIndexHint(q, j, ck.seg, segCapIn, cur);
       V3 o, d;
@@ -569,7 +570,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend(DevScene sc, DevCfg cfg, PixMap pm,
         o = cfg.cam.pos; d = xyz(sd); slot = f2u(sd.w);
       } else {
         float4 ro = wf.rayO[e], rd = wf.rayD[e];
-        o = xyz(ro); d = xyz(rd); slot = f2u(ro.w);
+        o = xyz(ro); d = xyz(rd); slot = f2u(ro.w); carry = rd.w;
       }
       isHit = traverse<false, LDSS, COUNT>(sc, o, d, cfg.eps, h, cN, cT);
       if (isHit) hitPos = o + d * h.t;
@@ -579,7 +580,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend(DevScene sc, DevCfg cfg, PixMap pm,
     if (isHit) {
       uint32_t e = outBase + idx;
       wf.hitA[e] = f4(hitPos, u2f(h.tri));
-      wf.hitB[e] = make_float4(h.u, h.v, u2f(slot), h.t);
+      wf.hitB[e] = make_float4(h.u, h.v, u2f(slot), PRIMARY ? h.t : carry);
     }
   }
   flushCounts<COUNT>(wf.stats, STAT_NODES_CLOSEST, cN, cT);
@@ -649,7 +650,7 @@ template <bool LDSS, bool COUNT>
 __global__ void PT_TRAVERSAL_BOUNDS k_connect(DevScene sc, float eps, QMeta q, uint32_t segCap, const float4* __restrict__ shO,
                                                   const float4* __restrict__ shD, const float4* __restrict__ shW,
                                                   uint32_t* taskCounter, float area, float4* __restrict__ Lacc,
-                                                  unsigned long long* stats) {
+                                                  uint32_t capSlots, uint32_t tag, unsigned long long* stats) {
   __shared__ __align__(16) WorkPool pool;
   initPool(&pool);
   stageScene<LDSS>(sc);
@@ -678,7 +679,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_connect(DevScene sc, float eps, QMeta q, u
           if (!(G > 0.0f)) G = 0.0f;
           V3 c = xyz(w) * Le * G * area;
           uint32_t slot = f2u(ro.w);
-          float4 L = Lacc[slot];
+          float4 L = loadLacc(Lacc, slot, capSlots, tag);
           L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z;
           Lacc[slot] = L;
         }
@@ -697,7 +698,8 @@ template <bool LDSS, bool COUNT>
 __global__ void PT_TRAVERSAL_BOUNDS k_occluded(DevScene sc, float eps, V3 sunRadiance, V3 skyRadiance, int direct, QMeta q,
                                                    uint32_t segCap, const float4* __restrict__ shO, const float4* __restrict__ shD,
                                                    const float4* __restrict__ shW, const float4* __restrict__ shX,
-                                                   uint32_t* taskCounter, float4* __restrict__ Lacc, unsigned long long* stats) {
+                                                   uint32_t* taskCounter, float4* __restrict__ Lacc, uint32_t capSlots, uint32_t tag,
+                                                   unsigned long long* stats) {
   __shared__ __align__(16) WorkPool pool;
   initPool(&pool);
   stageScene<LDSS>(sc);
@@ -726,7 +728,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_occluded(DevScene sc, float eps, V3 sunRad
         uint32_t slot = f2u(ro.w);
         V3 Tw; float4 L;
         if (direct) { V3 color = xyz(x); Tw = v3(1, 1, 1) * (PT_BRDF * color); L = make_float4(0.0f, 0.0f, 0.0f, x.w); }
-        else { Tw = xyz(x); L = Lacc[slot]; }
+        else { Tw = xyz(x); L = loadLacc(Lacc, slot, capSlots, tag); }
         if (vSun) { V3 c = Tw * sunRadiance * a.w; L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; }
         if (vSky) { V3 c = Tw * skyRadiance * b.w; L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; }
         Lacc[slot] = L;
@@ -744,8 +746,13 @@ struct ShadeCtx {
 };
 
 // One computeLindirect head (rendering.d:378-385): Russian roulette, direction, ray; appended to ray queue qOut.
+// FIRST: the chain starts here, at a view-ray hit whose material is firstMat.  Its throughput (the material's colour),
+// depth (1) and generator state (the chain's stream after these three draws) follow from the lane slot and that
+// material, so they are not stored: the ray carries firstMat in the free word of its direction record and the shading
+// of its hit works them out again (most such rays hit nothing and nobody would read what was stored).
+template <bool FIRST>
 __device__ __forceinline__ void bounce(ShadeCtx& cx, bool active, Rng& g, uint32_t depth, V3 T, V3 color, V3 pos, V3 normal,
-                                       uint32_t laneSlot) {
+                                       uint32_t laneSlot, uint32_t firstMat) {
   bool alive = false; V3 dir = v3(0, 0, 0);
   if (active) {
     float a = g.uniform(0.0f, 1.0f);
@@ -760,10 +767,12 @@ __device__ __forceinline__ void bounce(ShadeCtx& cx, bool active, Rng& g, uint32
   if (alive) {
     uint32_t e = cx.T * cx.segCapRay + idx;
     cx.wf.rayO[e] = f4(pos + normal * 0.1f, u2f(laneSlot));
-    cx.wf.rayD[e] = f4(dir, 0.0f);
-    // BRDF * PI * color == color: the factor the caller multiplies computeLrefl with (rendering.d:391)
-    cx.wf.thr[laneSlot] = f4(T * color, u2f(depth + 1));
-    cx.wf.rng[laneSlot] = make_uint2(g.s0, g.s1);
+    cx.wf.rayD[e] = f4(dir, FIRST ? u2f(firstMat) : 0.0f);
+    if (!FIRST) {
+      // BRDF * PI * color == color: the factor the caller multiplies computeLrefl with (rendering.d:391)
+      cx.wf.thr[laneSlot] = f4(T * color, u2f(depth + 1));
+      cx.wf.rng[laneSlot] = make_uint2(g.s0, g.s1);
+    }
   }
 }
 
@@ -863,6 +872,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg 
   const bool direct = envDirect(cfg, sc, PRIMARY);
   Task tk = taskOf(wf.hitQ, T);
   SegCursor seg = segCursor(wf.hitQ, tk.seg);
+  const FastDiv divCap = wf.divCap;
   if (T == 0 && threadIdx.x == 0) atomicAdd(&wf.stats[STAT_HITS], (unsigned long long)wf.hitQ.prefix[PT_SEGS]);
   for (uint32_t base = tk.begin; base < tk.end; base += blockDim.x) {
     uint32_t j = base + threadIdx.x;
@@ -882,6 +892,16 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg 
         sampleIdx = cfg.sampleBase + ((uint32_t)acc[gp].w + s) * cfg.sampleStride;
         g.seed(cfg.seed, gp, sampleIdx, 0);
         g.next(); g.next();                                            // the x and y jitter of getViewRay
+      } else if (wf.round == 0) {
+        // hit of a chain's first ray: what bounce<true> did not store
+        uint32_t chain = fdiv(divCap, laneSlot), slot = laneSlot - chain * wf.capSlots;         // chain = 1 + index
+        uint32_t s = fdiv(pm.divNpix, slot), lp = slot - s * pm.npix;
+        gp = mapPixel(pm, cfg.W, lp);
+        sampleIdx = cfg.sampleBase + ((uint32_t)acc[gp].w + s) * cfg.sampleStride;
+        g.seed(cfg.seed, gp, sampleIdx, chain);
+        g.next(); g.next(); g.next();                                  // Russian roulette, psi, phi of the chain's head
+        float4 m0 = tb.mat(f2u(hb.w));
+        Tp = v3(1, 1, 1) * v3(m0.y, m0.z, m0.w); depth = 1;
       } else {
         float4 t4 = wf.thr[laneSlot]; Tp = xyz(t4); depth = f2u(t4.w);
         uint2 r = wf.rng[laneSlot]; g.s0 = r.x; g.s1 = r.y;
@@ -902,11 +922,11 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg 
         for (uint32_t c = 0; c < cfg.numIndirect; c++) {               // the loop at rendering.d:474-476
           uint32_t lane = (c + 1) * wf.capSlots + laneSlot;
           Rng gc; gc.s0 = 1; gc.s1 = 0;
-          if (active) { gc.seed(cfg.seed, gp, sampleIdx, c + 1); wf.Lacc[lane] = make_float4(0, 0, 0, 0); }
-          bounce(cx, active, gc, 0, v3(1, 1, 1), color, hitPos, normal, lane);
+          if (active) gc.seed(cfg.seed, gp, sampleIdx, c + 1);
+          bounce<true>(cx, active, gc, 0, v3(1, 1, 1), color, hitPos, normal, lane, matTag - 1u);
         }
       } else {
-        bounce(cx, active, g, depth, Tp, color, hitPos, normal, laneSlot);
+        bounce<false>(cx, active, g, depth, Tp, color, hitPos, normal, laneSlot, 0u);
       }
     }
   }
@@ -944,7 +964,10 @@ __global__ void __launch_bounds__(256) k_accumulate(ViewMasks masks, DevCfg cfg,
       add = m.x * v3(m.y, m.z, m.w) + add;
       if (cfg.mode == 1) {
         V3 sum = v3(0, 0, 0);
-        for (uint32_t c = 0; c < cfg.numIndirect; c++) sum = sum + xyz(wf.Lacc[(size_t)(c + 1) * wf.capSlots + slot]);
+        for (uint32_t c = 0; c < cfg.numIndirect; c++) {
+          float4 Lc = wf.Lacc[(size_t)(c + 1) * wf.capSlots + slot];
+          sum = sum + (f2u(Lc.w) == wf.tag ? xyz(Lc) : v3(0, 0, 0));          // nothing was added to a record of another batch
+        }
         add = add + sum / (float)cfg.numIndirect;
       }
     }
@@ -1151,7 +1174,7 @@ void launchConnect(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, c
   Geo g = traversalGeo(lc, sc, wf.capQueue);
   size_t e = (size_t)kind * wf.capQueue;
   PT_DISPATCH_LC(k_connect, sc, cfg.eps, wf.sh[kind], wf.capQueue / PT_SEGS, (const float4*)(wf.shO + e), (const float4*)(wf.shD + e),
-                 (const float4*)(wf.shW + e), wf.taskCounters + 1 + kind, area, wf.Lacc, wf.stats);
+                 (const float4*)(wf.shW + e), wf.taskCounters + 1 + kind, area, wf.Lacc, wf.capSlots, wf.tag, wf.stats);
 }
 
 void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, bool primary) {
@@ -1159,7 +1182,7 @@ void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, 
   size_t e = (size_t)kind * wf.capQueue;
   PT_DISPATCH_LC(k_occluded, sc, cfg.eps, cfg.sunRadiance, cfg.skyRadiance, envDirect(cfg, sc, primary) ? 1 : 0, wf.sh[kind],
                  wf.capQueue / PT_SEGS, (const float4*)(wf.shO + e), (const float4*)(wf.shD + e), (const float4*)(wf.shW + e),
-                 (const float4*)wf.shX, wf.taskCounters + 1 + kind, wf.Lacc, wf.stats);
+                 (const float4*)wf.shX, wf.taskCounters + 1 + kind, wf.Lacc, wf.capSlots, wf.tag, wf.stats);
 }
 
 void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,

@@ -76,7 +76,7 @@ def main():
             if cyc:
                 d['waves_per_simd'] = round(per['SQ_WAVE_CYCLES'] * 4.0 / (1024.0 * cyc), 2)      # wave-cycles are counted in units of 4
         if per.get('SQ_LDS_IDX_ACTIVE') and cyc:
-            d['lds_busy'] = round(per['SQ_LDS_IDX_ACTIVE'] * 4.0 / (256.0 * cyc), 4) if per['SQ_LDS_IDX_ACTIVE'] else 0.0
+            d["lds_idx_active_per_cu_cycle"] = round(per["SQ_LDS_IDX_ACTIVE"] / (256.0 * cyc), 4)
             d['lds_bank_conflict_share'] = round(per.get('SQ_LDS_BANK_CONFLICT', 0.0) / per['SQ_LDS_IDX_ACTIVE'], 4)
         if per.get('TCC_HIT_sum') is not None and (per.get('TCC_HIT_sum', 0) + per.get('TCC_MISS_sum', 0)) > 0:
             d['l2_hit_rate'] = round(per['TCC_HIT_sum'] / (per['TCC_HIT_sum'] + per['TCC_MISS_sum']), 4)
