@@ -88,3 +88,20 @@ def test_too_many_emissive_materials_rejected():
     mats = np.tile(np.array([[1.0, 0.5, 0.5, 0.5]], np.float32), (T, 1))
     with pytest.raises(P.PtError):
         pt.upload_scene(v, v, np.arange(T, dtype=np.uint32), mats)
+
+
+def test_d_binding_text_follows_the_header():
+    """INTEGRATION.md's D module is what scripts/gen_d_binding.py makes of include/ptgpu.h: every constant, struct and
+    function of the header, nothing else."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('gen_d_binding', os.path.join(ROOT, 'scripts', 'gen_d_binding.py'))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    _, m = gen.integration_block()
+    assert m, 'INTEGRATION.md has no D block'
+    assert m.group(1) == gen.generate(), 'run `python3 scripts/gen_d_binding.py --update` after changing include/ptgpu.h'
+    dtext = m.group(1)
+    for name in declared_symbols():
+        assert re.search(r'\b%s\(' % name, dtext), name
+    for struct in ('PtConfig', 'PtStats', 'PtPixel', 'PtMaterial', 'PtHandle', 'PtGroup'):
+        assert 'struct ' + struct in dtext
+    assert dtext.count('sampleStride') == 1 and 'double maskBuildMs;' in dtext
