@@ -123,6 +123,12 @@ struct Hit { float t, u, v; uint32_t tri; bool front; };
 #ifndef PT_SHADE_THREADS
 #define PT_SHADE_THREADS 256
 #endif
+#if defined(PT_STAMP) || defined(PT_SLOTS)
+#define PT_STAMP_ON 1
+#else
+#define PT_STAMP_ON 0
+#endif
+
 
 // Traversal kernels are compiled for 8 waves per SIMD: two 1024-thread workgroups per CU when the scene copy in LDS
 // leaves room.  Besides 64 VGPRs this bounds the scalar registers: with more than 80 of them a SIMD holds only 7
@@ -238,13 +244,39 @@ __device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri
   uint32_t ref = sc.rootRef;
   if constexpr (!POSTPONE) {
     for (;;) {
-      while (isInternal(ref)) { if (COUNT) cN += 2; ref = stepDown<LDSS, OCT, ANY>(sc, ri, h.t, ref, stack, sp); }
+#ifdef PT_STAMP
+      // diagnostic build: cN / cT count the wave's clock ticks inside the descent loop and inside the leaf phase
+      // (whatever lane reports them: the wave spends them as a whole)
+      unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef PT_SLOTS
+      // diagnostic build: cN = lane steps taken, cT = lane slots the wave spent on them (64 per iteration of the
+      // descent loop, charged to the lowest lane in it)
+      for (;;) {
+        const bool in = isInternal(ref);
+        if (!__any(in)) break;
+        unsigned long long m = __ballot(1);
+        if (COUNT) {
+          if (!in) cN += 1;                              // slots a lane spends waiting at a leaf (steps taken: the normal counting build)
+          if (__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0) cT += 64;
+        }
+        if (in) ref = stepDown<LDSS, OCT, ANY>(sc, ri, h.t, ref, stack, sp);
+      }
+#else
+      while (isInternal(ref)) { if (COUNT && !PT_STAMP_ON) cN += 2; ref = stepDown<LDSS, OCT, ANY>(sc, ri, h.t, ref, stack, sp); }
+#endif
+#ifdef PT_STAMP
+      unsigned long long t1 = __builtin_amdgcn_s_memtime(); if (COUNT) cN += (uint32_t)(t1 - t0);
+#endif
       if (ref == PT_NONE) break;
       uint32_t cnt = ref >> BVH_COUNT_SHIFT, first = ref & BVH_INDEX_MASK;
       for (uint32_t i = 0; i < cnt; i++) {
-        if (COUNT) cT += 1;
+        if (COUNT && !PT_STAMP_ON) cT += 1;
         if (testTriangle<ANY, LDSS, BOTH>(sc, (first + i) * 3, o, d, eps, h, found)) return true;
       }
+#ifdef PT_STAMP
+      if (COUNT) cT += (uint32_t)(__builtin_amdgcn_s_memtime() - t1);
+#endif
       if (sp == 0) break;
       ref = popRef(stack, sp);
     }
