@@ -69,6 +69,9 @@ typedef struct PtConfig {
 #define PT_FLAG_GPU_BVH 16u       /* build the BVH on the GPU (Morton-order LBVH) whatever the scene size;
                                      default: on the GPU from 1 M triangles up, binned SAH on the host below */
 #define PT_FLAG_HOST_BVH 32u      /* always build the BVH on the host                                     */
+#define PT_FLAG_NO_GRAPH 64u      /* never replay a small batch from a HIP graph (default: a ptgpu_render / _bands call that is
+                                     one batch of at most 4 Mi samples is captured the second time it is issued with the
+                                     same arguments, scene, camera and configuration, and replayed from then on)     */
 
 typedef struct PtMaterial { float emissive; float color[3]; } PtMaterial;        /* rendering.d:33-37 */
 typedef struct PtPixel { float color[3]; float n; float sum[3]; } PtPixel;        /* rendering.d:24-30 */

@@ -92,6 +92,7 @@ bool isPinnedHost(const void* p) {
 }
 
 struct EventPair { hipEvent_t a, b; int kind; };
+constexpr uint64_t PT_GRAPH_MAX_SLOTS = 1ull << 22;       // batches up to this many samples are replayed from a graph
 constexpr int KIND_RENDER = PT_K_COUNT;       // span of one ptgpu_render call
 constexpr size_t MAX_EVENT_PAIRS = 16384;
 
@@ -125,6 +126,9 @@ struct PtHandle {
   DevBuf dPixelRec, dRgb[2]; PinnedBuf pinPixels, pinRgb[2];
   hipStream_t copyStream = nullptr; hipEvent_t evTone[2] = {nullptr, nullptr}, evCopy[2] = {nullptr, nullptr};
   int toneNext = 0, tonePending = -1; uint8_t* toneDst = nullptr; size_t toneBytes = 0; bool toneDirect = false;
+  // small batches (the progressive loop at the reference's frame size: a dozen launches of a few microseconds each)
+  // are replayed from a HIP graph: the first call of a shape runs normally, the second is captured, later ones replay
+  std::vector<uint8_t> graphSeen, graphKey; hipGraphExec_t graphExec = nullptr; uint64_t sceneGeneration = 0;
   bool noEvents = false;        // set while ptgpu_render_noalloc runs: no event is created or recorded
   // statistics
   PtStats st{};
@@ -319,7 +323,7 @@ void uploadScene(PtHandle* h) {
   d.numNodes = bvh.numNodes; d.numTris = NT; d.numOrigTris = T; d.rootRef = bvh.rootRef;
   d.numLightGroups = (uint32_t)lt.numGroups(); d.numMats = (uint32_t)fs.mats.size(); d.numLightTris = (uint32_t)lt.tris.size();
   for (int k = 0; k < 3; k++) { h->box.mn[k] = bvh.nodes[k]; h->box.mx[k] = bvh.nodes[4 + k]; }   // node 0 = root
-  h->haveScene = true;
+  h->haveScene = true; h->sceneGeneration++;
   h->st.numTriangles = T; h->st.numNodes = bvh.numNodes; h->st.bvhDepth = bvh.depth;
   h->st.numLightGroups = d.numLightGroups; h->st.sceneInLds = d.ldsBytes ? 1 : 0;
 }
@@ -498,6 +502,52 @@ void renderPixels(PtHandle* h, PixMap base, uint64_t totalPix, uint32_t spp, con
   uint64_t chunk = std::min<uint64_t>(cap, totalPix);
   if (wholeRows && chunk < totalPix && chunk >= 8ull * W) chunk -= chunk % (8ull * W);     // chunks of whole 8-row strips
   base.divBand = makeFastDiv(base.bandPix);
+  // ---- one small batch: replay it from a graph (launch-bound otherwise: ~13 launches for ~100 us of kernels) ----
+  const uint64_t nslotsAll = totalPix * spp;
+  const bool oneBatch = chunk == totalPix && nslotsAll <= cap;
+  if (!external && oneBatch && nslotsAll <= PT_GRAPH_MAX_SLOTS &&
+      !(h->cfg.flags & (PT_FLAG_TIME_KERNELS | PT_FLAG_COUNT_VISITS | PT_FLAG_NO_GRAPH))) {
+    PixMap pm = base; pm.lpBase = 0; pm.npix = (uint32_t)totalPix; pm.k = spp; pm.divNpix = makeFastDiv(pm.npix);
+    chooseTiling(pm, W, wholeRows);
+    std::vector<uint8_t> key;
+    auto put = [&](const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; key.insert(key.end(), b, b + n); };
+    // everything the launches of a batch take as arguments (the structs are assembled field by field from zeroed
+    // memory or copied whole, so equal contents mean equal bytes)
+    put(&pm, sizeof(pm)); put(&dc, sizeof(dc)); put(&ws.wf, sizeof(ws.wf)); put(&ws.masks, sizeof(ws.masks));
+    put(&h->acc, sizeof(h->acc)); put(&h->dsc, sizeof(h->dsc)); put(&h->box, sizeof(h->box)); put(&h->stream, sizeof(h->stream));
+    put(&h->sceneGeneration, sizeof(h->sceneGeneration)); put(&h->cfg.flags, sizeof(h->cfg.flags));
+    auto countBatch = [&]() { h->st.raysPrimary += nslotsAll; h->st.samples += nslotsAll; };
+    if (h->graphExec && key == h->graphKey) {
+      HIPCHECK(hipGraphLaunch(h->graphExec, h->stream));
+      countBatch(); span.done(); return;
+    }
+    if (key == h->graphSeen) {                 // second call of this shape: capture it
+      if (h->graphExec) { (void)hipGraphExecDestroy(h->graphExec); h->graphExec = nullptr; h->graphKey.clear(); }
+      hipGraph_t graph = nullptr;
+      HIPCHECK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+      try {
+        // chain radiance records are told apart by the batch tag, which is fixed in a captured launch: clear the part
+        // of them this batch uses, so that a replay never meets its own tag from the replay before
+        for (uint32_t c = 1; c < ws.wf.lanes; c++)
+          HIPCHECK(hipMemsetAsync(ws.wf.Lacc + (size_t)c * ws.wf.capSlots, 0, (size_t)nslotsAll * 16, h->stream));
+        h->noEvents = true;
+        renderBatch(h, dc, lc, pm, ws);
+        h->noEvents = false;
+      } catch (...) {
+        h->noEvents = false;
+        (void)hipStreamEndCapture(h->stream, &graph); if (graph) (void)hipGraphDestroy(graph);
+        throw;
+      }
+      HIPCHECK(hipStreamEndCapture(h->stream, &graph));
+      hipError_t ge = hipGraphInstantiate(&h->graphExec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (ge != hipSuccess) { h->graphExec = nullptr; fail(PT_E_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(ge)); }
+      h->graphKey = key;
+      HIPCHECK(hipGraphLaunch(h->graphExec, h->stream));
+      span.done(); return;                     // (renderBatch has counted the batch while it was captured)
+    }
+    h->graphSeen = key;                        // first call: run it as usual (this also sets kernel attributes)
+  }
   for (uint64_t lp0 = 0; lp0 < totalPix; lp0 += chunk) {
     uint32_t npix = (uint32_t)std::min<uint64_t>(chunk, totalPix - lp0);
     uint32_t kmax = std::max<uint32_t>(1u, (uint32_t)(cap / npix));
@@ -570,6 +620,7 @@ int ptgpu_destroy(PtHandle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (EventPair& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (hipEvent_t e : h->freeEvents) (void)hipEventDestroy(e);
+    if (h->graphExec) (void)hipGraphExecDestroy(h->graphExec);
     if (h->copyStream) { (void)hipStreamSynchronize(h->copyStream); (void)hipStreamDestroy(h->copyStream); }
     for (int k = 0; k < 2; k++) { if (h->evTone[k]) (void)hipEventDestroy(h->evTone[k]); if (h->evCopy[k]) (void)hipEventDestroy(h->evCopy[k]); }
     if (h->ownStream && h->stream) (void)hipStreamDestroy(h->stream);

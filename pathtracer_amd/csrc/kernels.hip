@@ -446,12 +446,15 @@ __device__ __forceinline__ bool nextChunk(WorkPool* p, uint32_t* counter, const 
         st = vp->state;
         if ((uint32_t)st >= (uint32_t)(st >> 32) && !vp->done) {
           bool full = outLimit && vp->out + blockDim.x + PT_SUPER > outLimit;   // + blockDim.x: chunks in flight
-          uint32_t g = full ? 0xFFFFFFFFu : atomicAdd(counter, PT_SUPER);
+          // a short queue is handed out in smaller pieces, so that every workgroup of the launch gets some of it: with
+          // PT_SUPER entries a piece, 76 800 rays (a 320 x 240 pass) would keep 38 workgroups busy and leave the rest idle
+          const uint32_t piece = min(PT_SUPER, max(blockDim.x, ((total + gridDim.x - 1) / gridDim.x + 63u) & ~63u));
+          uint32_t g = full ? 0xFFFFFFFFu : atomicAdd(counter, piece);
           if (g >= total) vp->done = 1;
           else {
             vp->seg = q.start[g / q.prefix[PT_SEGS + 1]];
             __threadfence_block();
-            atomicExch(&p->state, ((unsigned long long)min(g + PT_SUPER, total) << 32) | g);
+            atomicExch(&p->state, ((unsigned long long)min(g + piece, total) << 32) | g);
           }
         }
         __threadfence_block();

@@ -366,3 +366,38 @@ def test_native_group_of_one_gpu_equals_a_single_handle(require_gpu, split):
 def conftest_model(name):
     from conftest import model_path
     return model_path(name)
+
+
+@pytest.mark.parametrize('name,sky,mode', [('cornell-box', 0, 0), ('teapot', 1, 0), ('chest1', 1, 1), ('cornell-box', 0, 1)])
+def test_repeated_small_passes_replayed_from_a_graph_equal_one_render(require_gpu, name, sky, mode):
+    """The progressive loop (main.d:273-287) issues the same one-sample pass again and again; from its second
+    occurrence such a call is captured into a HIP graph and replayed.  Six passes equal one render of six samples bit for
+    bit, also with the graph switched off, with a window in between (another shape: no replay) and after a camera change."""
+    W, H = 160, 120
+    want = make_tracer(name, W, H, has_sky=sky, mode=mode, seed=17, flags=P.PT_FLAG_NO_GRAPH); want.render_frame(6)
+    ref = want.read_pixels()
+    pt = make_tracer(name, W, H, has_sky=sky, mode=mode, seed=17)
+    for _ in range(3):
+        pt.render_frame(1)
+    pt.render(0, 7 * W, 1)                                          # a different shape in between
+    for _ in range(3):
+        pt.render_frame(1)
+    pt.render(7 * W, (H - 7) * W, 1)
+    got = pt.read_pixels()
+    assert (got['n'] == 7).all()
+    full = make_tracer(name, W, H, has_sky=sky, mode=mode, seed=17, flags=P.PT_FLAG_NO_GRAPH); full.render_frame(7)
+    assert np.array_equal(got['sum'].view(np.uint32), full.read_pixels()['sum'].view(np.uint32))
+    six = make_tracer(name, W, H, has_sky=sky, mode=mode, seed=17)
+    for _ in range(6):
+        six.render_frame(1)
+    assert np.array_equal(six.read_pixels()['sum'].view(np.uint32), ref['sum'].view(np.uint32))
+    # camera change: the captured launches hold the old camera, so the shape is captured anew
+    cam2 = P.Camera(30.0, H / W).setTransform((CAMERAS[name][0][0] + 1.0, CAMERAS[name][0][1], CAMERAS[name][0][2]), CAMERAS[name][1], (0, 0, 1))
+    a = make_tracer(name, W, H, has_sky=sky, mode=mode, seed=17); b = make_tracer(name, W, H, has_sky=sky, mode=mode, seed=17, flags=P.PT_FLAG_NO_GRAPH)
+    for t in (a, b):
+        for _ in range(3):
+            t.render_frame(1)
+        t.clear_pixels(); t.set_camera(cam2)
+        for _ in range(3):
+            t.render_frame(1)
+    assert np.array_equal(a.read_pixels()['sum'].view(np.uint32), b.read_pixels()['sum'].view(np.uint32))
