@@ -2,6 +2,7 @@
 #include "../../include/ptgpu.h"
 #include "kernels.h"
 #include "bvh_gpu.h"
+#include "mask_gpu.h"
 #include "scene_host.h"
 #include "thmodel.h"
 #include <hip/hip_runtime.h>
@@ -114,6 +115,7 @@ struct PtHandle {
   SceneBox box{};
   // coverage mask of the view rays (scene_host.h: buildCoverageMask); rebuilt when the scene or the camera changes
   DevBuf dMask, dSkyMask; bool maskDirty = true, maskUsable = false;
+  DevBuf dVerts, dMaskRows, dMaskBig, dMaskFlags; double sceneScale = 0.0;   // for the GPU build of the masks (mask_gpu.h)
   DevBuf dTex; bool texDirty = true;   // TriangleData.tex in input order, uploaded at the first texcoord trace
   ViewMasks masks() const { return maskUsable ? ViewMasks{dMask.as<uint32_t>(), dSkyMask.as<uint32_t>()} : ViewMasks{nullptr, nullptr}; }
   DevBuf bMetaDesc; std::vector<QMeta> metas;     // queue descriptors: device copy and host copy, stage-major
@@ -308,6 +310,9 @@ void uploadScene(PtHandle* h) {
     up(h->dNodes, q.data(), q.size() * 4);
   }
   up(h->dTris, tris.data(), tris.size() * 4);
+  if (fs.v.empty()) h->dVerts.alloc(16);
+  else up(h->dVerts, fs.v.data(), fs.v.size() * 4);                          // input order and bits: what the masks project
+  h->sceneScale = sceneScale(fs);
   up(h->dNrm, nrm.data(), nrm.size() * 4);
   up(h->dMats, mats.data(), mats.size() * 4);
   up(h->dLights, lights.data(), lights.size() * 4);
@@ -469,6 +474,26 @@ void chooseTiling(PixMap& pm, uint32_t W, bool wholeRows) {
   pm.divTilesPerRow = makeFastDiv(pm.tilesPerRow);
 }
 
+// The view-ray masks for the current scene and camera, built on the GPU (mask_gpu.h) on the handle's stream; the call
+// waits for that stream once, to learn whether the masks are usable at all (no triangle behind the camera plane).
+void buildMasks(PtHandle* h) {
+  const auto tMask = std::chrono::steady_clock::now();
+  h->maskUsable = false;
+  if (!(h->cfg.flags & PT_FLAG_NO_COVERAGE_MASK)) {
+    const uint32_t W = h->cfg.width, H = h->cfg.height, T = (uint32_t)h->flat.numTriangles();
+    const size_t words = ((size_t)W * H + 31) / 32;
+    h->dMask.alloc(words * 4); h->dSkyMask.alloc(words * 4);
+    h->dMaskRows.alloc(maskRowWords(W, H) * 4); h->dMaskBig.alloc(std::max<size_t>(T, 1) * 4); h->dMaskFlags.alloc(8);
+    bool usable = false;
+    HIPCHECK(buildCoverageMaskGpu(h->stream, h->dVerts.as<float>(), T, h->cam, W, H, h->sceneScale, h->dMaskRows.as<uint32_t>(),
+                                  h->dMaskBig.as<uint32_t>(), h->dMaskFlags.as<uint32_t>(), h->dMask.as<uint32_t>(),
+                                  h->dSkyMask.as<uint32_t>(), &usable));
+    h->maskUsable = usable;
+  }
+  h->maskDirty = false;
+  h->st.maskBuildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tMask).count();
+}
+
 // external: the batch state to use instead of the handle's own (the caller has laid it out); nothing is allocated,
 // built on the host or timed with events on that path.
 void renderPixels(PtHandle* h, PixMap base, uint64_t totalPix, uint32_t spp, const WfState* external = nullptr,
@@ -477,20 +502,7 @@ void renderPixels(PtHandle* h, PixMap base, uint64_t totalPix, uint32_t spp, con
   if (!h->haveCamera) fail(PT_E_STATE, "no camera: call ptgpu_set_camera or ptgpu_camera_look_at first");
   if (totalPix == 0 || spp == 0) return;
   if (!external) ensureWavefront(h);
-  if (!external && h->maskDirty) {
-    const auto tMask = std::chrono::steady_clock::now();
-    std::vector<uint32_t> bits, sky;
-    h->maskUsable = !(h->cfg.flags & PT_FLAG_NO_COVERAGE_MASK) &&
-                    buildCoverageMask(h->flat, h->cam, h->cfg.width, h->cfg.height, bits, sky);
-    if (h->maskUsable) {
-      HIPCHECK(hipStreamSynchronize(h->stream));
-      h->dMask.alloc(bits.size() * 4); h->dSkyMask.alloc(sky.size() * 4);
-      HIPCHECK(hipMemcpy(h->dMask.p, bits.data(), bits.size() * 4, hipMemcpyHostToDevice));
-      HIPCHECK(hipMemcpy(h->dSkyMask.p, sky.data(), sky.size() * 4, hipMemcpyHostToDevice));
-    }
-    h->maskDirty = false;
-    h->st.maskBuildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tMask).count();
-  }
+  if (!external && h->maskDirty) buildMasks(h);
   DevCfg dc = makeDevCfg(h); LaunchCfg lc = makeLaunchCfg(h);
   lc.maxGroups = maxGroups;
   WfState own{h->wf, h->metas.data(), h->bMetaDesc.as<QMeta>(), h->masks()};
@@ -1105,7 +1117,17 @@ int ptgpu_get_coverage_mask(PtHandle* h, uint32_t* covered, uint32_t* constantSk
     if (!h || !usable) fail(PT_E_INVALID, "null argument");
     if (!h->haveScene) fail(PT_E_STATE, "no scene");
     if (!h->haveCamera) fail(PT_E_STATE, "no camera");
-    std::vector<uint32_t> m, s;
+    if (h->cfg.device >= 0 && !(h->cfg.flags & PT_FLAG_NO_COVERAGE_MASK)) {     // the masks rendering uses: built on the GPU
+      useDevice(h);
+      if (h->maskDirty) buildMasks(h);
+      *usable = h->maskUsable ? 1u : 0u;
+      const size_t bytes = (((size_t)h->cfg.width * h->cfg.height + 31) / 32) * 4;
+      HIPCHECK(hipStreamSynchronize(h->stream));
+      if (h->maskUsable && covered) HIPCHECK(hipMemcpy(covered, h->dMask.p, bytes, hipMemcpyDeviceToHost));
+      if (h->maskUsable && constantSky) HIPCHECK(hipMemcpy(constantSky, h->dSkyMask.p, bytes, hipMemcpyDeviceToHost));
+      return;
+    }
+    std::vector<uint32_t> m, s;                       // host-only handle (or masks switched off): the host builder
     bool ok = buildCoverageMask(h->flat, h->cam, h->cfg.width, h->cfg.height, m, s);
     *usable = ok ? 1u : 0u;
     if (ok && covered) std::memcpy(covered, m.data(), m.size() * 4);

@@ -1,4 +1,6 @@
 #include "scene_host.h"
+#include "mask_math.h"
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <functional>
@@ -189,79 +191,27 @@ Camera cameraLookAt(float fovDegrees, float aspect, V3 from, V3 to, V3 up) {
   return c;
 }
 
-bool buildCoverageMask(const FlatScene& scene, const Camera& cam, uint32_t W, uint32_t H, std::vector<uint32_t>& bits,
-                       std::vector<uint32_t>& constantSky) {
-  // A view ray through screen position (x, y) has direction dir + right*(x*tanFov) + up*(y*tanFov*aspect)
-  // (camera.d:38-42).  Point p (relative to the camera) lies on it iff p = t*(dir + a*right + b*up) with t > 0,
-  // x = a/tanFov, y = b/(tanFov*aspect): solve with the inverse of the matrix whose columns are dir, right, up.
-  const double m[3][3] = {{cam.dir.x, cam.right.x, cam.up.x}, {cam.dir.y, cam.right.y, cam.up.y}, {cam.dir.z, cam.right.z, cam.up.z}};
-  double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
-               m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
-  double sx = (double)cam.tanFov, sy = (double)cam.tanFov * (double)cam.aspect;
-  if (!(std::fabs(det) > 1e-12) || !(std::fabs(sx) > 1e-12) || !(std::fabs(sy) > 1e-12)) return false;
-  double inv[3][3];
-  inv[0][0] = (m[1][1] * m[2][2] - m[1][2] * m[2][1]) / det; inv[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) / det;
-  inv[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) / det; inv[1][0] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) / det;
-  inv[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) / det; inv[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) / det;
-  inv[2][0] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) / det; inv[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) / det;
-  inv[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) / det;
-
-  // scene scale: a vertex closer to the camera plane than this is treated as "not in front"
+double sceneScale(const FlatScene& scene) {
   double scale = 1e-30;
   for (float f : scene.v) if (std::isfinite(f)) scale = std::max(scale, (double)std::fabs(f));
-  scale = std::max({scale, (double)std::fabs(cam.pos.x), (double)std::fabs(cam.pos.y), (double)std::fabs(cam.pos.z)});
-  const double tMin = 1e-6 * scale;
+  return scale;
+}
 
+bool buildCoverageMask(const FlatScene& scene, const Camera& cam, uint32_t W, uint32_t H, std::vector<uint32_t>& bits,
+                       std::vector<uint32_t>& constantSky) {
+  MaskCam mc;
+  if (!maskCamSetup(cam, W, H, sceneScale(scene), mc)) return false;
   const size_t wordsPerRow = ((size_t)W + 31) / 32;           // rows are padded to whole words while marking
   std::vector<uint32_t> rows((size_t)H * wordsPerRow, 0u);
-  // sample positions of pixel (col, row): x in col*2/W - 1 + [-1/W, 1/W), i.e. within half a pixel of the pixel's
-  // nominal position; margin: 0.05 pixel for the fp32 rounding of the device's ray set-up and triangle test
-  const double margin = 0.55;
   size_t T = scene.numTriangles();
   for (size_t i = 0; i < T; i++) {
-    const float* p = &scene.v[9 * i];
-    bool finite = true;
-    for (int k = 0; k < 9; k++) finite = finite && std::isfinite(p[k]);
-    if (!finite) continue;                                    // never hit (no BVH leaf holds it)
-    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300, vx[3], vy[3];
-    for (int v = 0; v < 3; v++) {
-      double q[3] = {(double)p[3 * v] - cam.pos.x, (double)p[3 * v + 1] - cam.pos.y, (double)p[3 * v + 2] - cam.pos.z};
-      double t = inv[0][0] * q[0] + inv[0][1] * q[1] + inv[0][2] * q[2];
-      double a = inv[1][0] * q[0] + inv[1][1] * q[1] + inv[1][2] * q[2];
-      double b = inv[2][0] * q[0] + inv[2][1] * q[1] + inv[2][2] * q[2];
-      if (!(t > tMin)) return false;
-      double px = (a / (t * sx) + 1.0) * 0.5 * (double)W, py = (b / (t * sy) + 1.0) * 0.5 * (double)H;   // in pixels
-      vx[v] = px; vy[v] = py;
-      x0 = std::min(x0, px); x1 = std::max(x1, px); y0 = std::min(y0, py); y1 = std::max(y1, py);
-    }
-    double c0 = std::ceil(x0 - margin), c1 = std::floor(x1 + margin), r0 = std::ceil(y0 - margin), r1 = std::floor(y1 + margin);
-    if (c1 < 0 || r1 < 0 || c0 > (double)W - 1 || r0 > (double)H - 1) continue;
-    uint32_t ca = (uint32_t)std::max(0.0, c0), cb = (uint32_t)std::min((double)W - 1, c1);
-    uint32_t ra = (uint32_t)std::max(0.0, r0), rb = (uint32_t)std::min((double)H - 1, r1);
-    if (ca > cb || ra > rb) continue;
-    // Inside that rectangle, the pixels whose square of sample positions (half size = margin) reaches the projected
-    // triangle: for every edge, the corner of the square farthest to the inner side must not be outside of it.  All
-    // vertices are in front of the camera, so the projection of the triangle is the triangle of the projections.
-    // E_k(x, y) = A_k x + B_k y + C_k >= 0 inside; a sliver (no usable orientation) keeps the whole rectangle.
-    double A[3], B[3], C[3];
-    double area2 = (vx[1] - vx[0]) * (vy[2] - vy[0]) - (vx[2] - vx[0]) * (vy[1] - vy[0]);
-    bool edges = std::fabs(area2) > 1e-9;
-    for (int k = 0; k < 3 && edges; k++) {
-      int k1 = (k + 1) % 3;
-      double sgn = area2 > 0.0 ? 1.0 : -1.0;
-      A[k] = sgn * (vy[k] - vy[k1]); B[k] = sgn * (vx[k1] - vx[k]); C[k] = -(A[k] * vx[k] + B[k] * vy[k]);
-    }
-    for (uint32_t r = ra; r <= rb; r++) {
-      double lo = (double)ca, hi = (double)cb;
-      for (int k = 0; k < 3 && edges; k++) {
-        double reach = margin * (std::fabs(A[k]) + std::fabs(B[k]));
-        double kk = B[k] * (double)r + C[k] + reach + 1e-9 * (std::fabs(A[k]) + std::fabs(B[k]) + std::fabs(C[k]) + 1.0);
-        if (A[k] > 0.0) lo = std::max(lo, std::ceil(-kk / A[k] - 1e-9));
-        else if (A[k] < 0.0) hi = std::min(hi, std::floor(-kk / A[k] + 1e-9));
-        else if (kk < 0.0) hi = lo - 1.0;
-      }
-      if (!(lo <= hi)) continue;
-      uint32_t a = (uint32_t)lo, b = (uint32_t)hi;
+    MaskTri t;
+    int st = maskTriSetup(mc, &scene.v[9 * i], t);
+    if (st == MASK_TRI_BEHIND) return false;
+    if (st != MASK_TRI_OK) continue;
+    for (uint32_t r = t.ra; r <= t.rb; r++) {
+      uint32_t a, b;
+      if (!maskRowSpan(t, r, a, b)) continue;
       uint32_t wa = a >> 5, wb = b >> 5;
       uint32_t first = 0xFFFFFFFFu << (a & 31), last = 0xFFFFFFFFu >> (31 - (b & 31));
       uint32_t* row = &rows[(size_t)r * wordsPerRow];
@@ -269,31 +219,16 @@ bool buildCoverageMask(const FlatScene& scene, const Camera& cam, uint32_t W, ui
       else { row[wa] |= first; for (uint32_t w = wa + 1; w < wb; w++) row[w] = 0xFFFFFFFFu; row[wb] |= last; }
     }
   }
-  // repack to one bit per pixel index (row * W + col); constantSky: not covered and no sample position of the pixel
-  // can see sampleSky's sun disc (dot(normalized(1,1,6), d) > 0.997, rendering.d:332-339).  The direction of a
-  // sample differs from that of the pixel's nominal position by an angle of at most delta / (|v| - delta), v the
-  // un-normalised direction and delta the length of the jitter's offset to it; a cosine changes by no more than
-  // the angle does.
+  // repack to one bit per pixel index (row * W + col)
   size_t npix = (size_t)W * H;
   bits.assign((npix + 31) / 32, 0u);
   constantSky.assign((npix + 31) / 32, 0u);
-  const double sun[3] = {1.0 / std::sqrt(38.0), 1.0 / std::sqrt(38.0), 6.0 / std::sqrt(38.0)};
-  const double rl = std::sqrt((double)dot(cam.right, cam.right)), ul = std::sqrt((double)dot(cam.up, cam.up));
-  const double delta = std::sqrt((rl * sx / W) * (rl * sx / W) + (ul * sy / H) * (ul * sy / H));
-  for (uint32_t r = 0; r < H; r++) {
-    double y = (double)r / H * 2.0 - 1.0;
+  for (uint32_t r = 0; r < H; r++)
     for (uint32_t c = 0; c < W; c++) {
       size_t px = (size_t)r * W + c;
       if ((rows[(size_t)r * wordsPerRow + (c >> 5)] >> (c & 31)) & 1u) { bits[px >> 5] |= 1u << (px & 31); continue; }
-      double x = (double)c / W * 2.0 - 1.0;
-      double v[3] = {cam.dir.x + cam.right.x * x * sx + cam.up.x * y * sy, cam.dir.y + cam.right.y * x * sx + cam.up.y * y * sy,
-                     cam.dir.z + cam.right.z * x * sx + cam.up.z * y * sy};
-      double len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-      if (!(len > 2.0 * delta)) continue;                                  // degenerate direction: leave it to the kernel
-      double cosSun = (v[0] * sun[0] + v[1] * sun[1] + v[2] * sun[2]) / len;
-      if (cosSun + delta / (len - delta) + 1e-5 < 0.997) constantSky[px >> 5] |= 1u << (px & 31);
+      if (maskConstantSky(mc, c, r)) constantSky[px >> 5] |= 1u << (px & 31);
     }
-  }
   return true;
 }
 

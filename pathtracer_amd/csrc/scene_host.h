@@ -51,6 +51,8 @@ Camera cameraLookAt(float fovDegrees, float aspect, V3 from, V3 to, V3 up);
 // in addition no sample position of the pixel sees sampleSky's sun disc (rendering.d:332-339): every sample of that
 // pixel is the sky constant.  Returns false (outputs unspecified) when the masks cannot be built: a triangle is not
 // strictly in front of the camera, or the camera basis is singular.
+// Largest finite |coordinate| of the scene (the masks' notion of its scale).
+double sceneScale(const FlatScene& scene);
 bool buildCoverageMask(const FlatScene& scene, const Camera& cam, uint32_t W, uint32_t H, std::vector<uint32_t>& bits,
                        std::vector<uint32_t>& constantSky);
 
