@@ -881,12 +881,17 @@ void orc_bvh_count(void* h, const float* nodes8, uint32_t rootRef, const uint32_
   uint64_t cN = 0, cT = 0;
   for (uint32_t ri = 0; ri < count; ri++) {
     const float* p = rays6 + 6 * (size_t)ri; Ray r{v3(p[0], p[1], p[2]), v3(p[3], p[4], p[5])};
-    float d[3] = {r.d.x, r.d.y, r.d.z}, o[3] = {r.o.x, r.o.y, r.o.z}, inv[3], oi[3];
-    for (int k = 0; k < 3; k++) { float dk = fabsf(d[k]) < 1e-20f ? copysignf(1e-20f, d[k]) : d[k]; inv[k] = 1.0f / dk; oi[k] = -o[k] * inv[k]; }
+    float d[3] = {r.d.x, r.d.y, r.d.z}, o[3] = {r.o.x, r.o.y, r.o.z}, inv[3], a0[3], a1[3];
+    float om = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fabsf(o[2]));
+    for (int k = 0; k < 3; k++) {      // the kernels' addends: -o/d moved apart by 4 ulp of max|o| / |d| towards "enters earlier, leaves later"
+      float dk = fabsf(d[k]) < 1e-20f ? copysignf(1e-20f, d[k]) : d[k]; inv[k] = 1.0f / dk;
+      float oi = -o[k] * inv[k], s = om * fabsf(inv[k]) * 2.4e-7f;
+      a0[k] = inv[k] > 0.0f ? oi - s : oi + s; a1[k] = inv[k] > 0.0f ? oi + s : oi - s;
+    }
     float bt = FLT_MAX; int btri = -1; uint32_t stack[64]; int sp = 0; uint32_t ref = rootRef; bool live = true, done = false;
     auto slab = [&](const float* n, float& tn) {
       float lo[3], hi[3];
-      for (int k = 0; k < 3; k++) { float a = std::fmaf(n[k], inv[k], oi[k]), b = std::fmaf(n[4 + k], inv[k], oi[k]); lo[k] = fminf(a, b); hi[k] = fmaxf(a, b); }
+      for (int k = 0; k < 3; k++) { float a = std::fmaf(n[k], inv[k], a0[k]), b = std::fmaf(n[4 + k], inv[k], a1[k]); lo[k] = fminf(a, b); hi[k] = fmaxf(a, b); }
       tn = fmaxf(fmaxf(lo[0], lo[1]), fmaxf(lo[2], 0.0f));
       float tf = fminf(fminf(hi[0], hi[1]), hi[2]) * 1.0000005f;
       if (anyHit) return !(tn > tf);

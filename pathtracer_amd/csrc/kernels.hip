@@ -71,14 +71,33 @@ template <bool LDSS> __device__ __forceinline__ void stageScene(const DevScene& 
 }
 
 // Reciprocal direction for the slab test.  Only the (conservative) box test uses it, never the triangle test.
-struct RayInv { float ix, iy, iz, ox, oy, oz; };
-__device__ __forceinline__ RayInv makeRayInv(V3 o, V3 d) {
+// A plane at coordinate c is crossed at t = c * i + a.  Every axis has two addends: one for the plane at the box's
+// minimum (a0) and one for the plane at its maximum (a1).  They are -o * i moved apart by a slack towards "earlier" for
+// the plane the ray enters through and "later" for the one it leaves through: the triangle test subtracts the origin
+// from the vertices in fp32, i.e. it answers for a ray whose origin is off by up to an ulp of the origin's
+// coordinates -- of its largest coordinate on every axis, because the test's dot products mix the axes -- and the box
+// test must not cull what that test accepts; the padding of the boxes (relative to the scene) covers that only while
+// the origin is not much farther away than the scene is large.  The slack is 4 ulp of max|o| * |i| per axis (plus the
+// same for the offset of a quantised grid): next to nothing for rays that start inside the scene, and it costs no
+// instruction in the box test.  It keeps the traversal's answer equal to the exhaustive search's up to origins about
+// 10^3 scene extents away; from about 10^4 on the triangle test itself accepts triangles that the exact ray misses by
+// a tenth of the scene, which no box test can follow.
+struct RayInv { float ix, iy, iz, a0x, a0y, a0z, a1x, a1y, a1z; };
+__device__ __forceinline__ RayInv makeRayInv(V3 o, V3 d, V3 gridBase = v3(0, 0, 0)) {
   float dx = fabsf(d.x) < 1e-20f ? copysignf(1e-20f, d.x) : d.x;
   float dy = fabsf(d.y) < 1e-20f ? copysignf(1e-20f, d.y) : d.y;
   float dz = fabsf(d.z) < 1e-20f ? copysignf(1e-20f, d.z) : d.z;
   RayInv r;
   r.ix = __builtin_amdgcn_rcpf(dx); r.iy = __builtin_amdgcn_rcpf(dy); r.iz = __builtin_amdgcn_rcpf(dz);
-  r.ox = -o.x * r.ix; r.oy = -o.y * r.iy; r.oz = -o.z * r.iz;
+  const float ox = -o.x * r.ix, oy = -o.y * r.iy, oz = -o.z * r.iz;
+  const float k = 2.4e-7f;                                          // 4 * 2^-24
+  const float om = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+  const float sx = (om + fabsf(gridBase.x)) * fabsf(r.ix) * k, sy = (om + fabsf(gridBase.y)) * fabsf(r.iy) * k,
+              sz = (om + fabsf(gridBase.z)) * fabsf(r.iz) * k;
+  // i > 0: the ray enters through the minimum plane
+  r.a0x = r.ix > 0.0f ? ox - sx : ox + sx; r.a1x = r.ix > 0.0f ? ox + sx : ox - sx;
+  r.a0y = r.iy > 0.0f ? oy - sy : oy + sy; r.a1y = r.iy > 0.0f ? oy + sy : oy - sy;
+  r.a0z = r.iz > 0.0f ? oz - sz : oz + sz; r.a1z = r.iz > 0.0f ? oz + sz : oz - sz;
   return r;
 }
 // Direction octant: bit k set when component k of the (reciprocal) direction is negative.
@@ -92,9 +111,9 @@ __device__ __forceinline__ uint32_t octantOf(const RayInv& r) {
 template <int OCT = -1, bool UNBOUNDED = false>
 __device__ __forceinline__ bool slab(const RayInv& r, float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
                                      float tmax, float& tn) {
-  float p0x = fmaf(mnx, r.ix, r.ox), p1x = fmaf(mxx, r.ix, r.ox);
-  float p0y = fmaf(mny, r.iy, r.oy), p1y = fmaf(mxy, r.iy, r.oy);
-  float p0z = fmaf(mnz, r.iz, r.oz), p1z = fmaf(mxz, r.iz, r.oz);
+  float p0x = fmaf(mnx, r.ix, r.a0x), p1x = fmaf(mxx, r.ix, r.a1x);
+  float p0y = fmaf(mny, r.iy, r.a0y), p1y = fmaf(mxy, r.iy, r.a1y);
+  float p0z = fmaf(mnz, r.iz, r.a0z), p1z = fmaf(mxz, r.iz, r.a1z);
   float nx, ny, nz, fx, fy, fz;
   if constexpr (OCT < 0) {
     nx = fminf(p0x, p1x); fx = fmaxf(p0x, p1x);
@@ -308,11 +327,11 @@ __device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri
 // stand-alone variants, the general one.  Must be called with the lanes that have a ray active and no others.
 template <bool ANY, bool LDSS, bool COUNT, bool BY_OCTANT = !COUNT && !ANY, bool BOTH = false>
 __device__ __forceinline__ bool traverse(const DevScene& sc, V3 o, V3 d, float eps, Hit& h, uint32_t& cN, uint32_t& cT) {
-  RayInv ri = makeRayInv(o, d);
+  RayInv ri = makeRayInv(o, d, LDSS ? v3(0, 0, 0) : v3(sc.qBase[0], sc.qBase[1], sc.qBase[2]));
   if constexpr (!LDSS) {     // box planes come as grid coordinates q: plane = qBase + q * qScale
-    ri.ox = fmaf(sc.qBase[0], ri.ix, ri.ox); ri.ix = sc.qScale[0] * ri.ix;
-    ri.oy = fmaf(sc.qBase[1], ri.iy, ri.oy); ri.iy = sc.qScale[1] * ri.iy;
-    ri.oz = fmaf(sc.qBase[2], ri.iz, ri.oz); ri.iz = sc.qScale[2] * ri.iz;
+    ri.a0x = fmaf(sc.qBase[0], ri.ix, ri.a0x); ri.a1x = fmaf(sc.qBase[0], ri.ix, ri.a1x); ri.ix = sc.qScale[0] * ri.ix;
+    ri.a0y = fmaf(sc.qBase[1], ri.iy, ri.a0y); ri.a1y = fmaf(sc.qBase[1], ri.iy, ri.a1y); ri.iy = sc.qScale[1] * ri.iy;
+    ri.a0z = fmaf(sc.qBase[2], ri.iz, ri.a0z); ri.a1z = fmaf(sc.qBase[2], ri.iz, ri.a1z); ri.iz = sc.qScale[2] * ri.iz;
   }
   if constexpr (BY_OCTANT) {
     uint32_t oct = octantOf(ri), o0 = __builtin_amdgcn_readfirstlane(oct);

@@ -366,3 +366,38 @@ def test_view_ray_masks_built_on_the_gpu_equal_the_host_builder(require_gpu, cas
         assert a[0].any() and (a[1].any() or case == "cornell-box")         # the cornell room fills the frame
         dev.render_frame(1)
         assert dev.stats().maskBuildMs >= 0.0
+
+
+@pytest.mark.parametrize('lds', [True, False])
+def test_rays_that_start_far_from_the_scene(require_gpu, lds, flats):
+    """Origins 10^2 and 10^3 scene extents away: the triangle test subtracts the origin in fp32, so it answers for a ray
+    whose origin is off by an ulp of those large coordinates; the box test widens by that much (RayInv in kernels.hip)
+    instead of relying on the scene-relative padding of the boxes, so the traversal still finds exactly what the
+    exhaustive oracle accepts.  At 10^4 extents the triangle test itself (scene.d:60-105 restated) accepts triangles
+    that the exact ray misses by a tenth of the scene -- cancellation in its dot products -- so a traversal that visits
+    only the boxes near the ray cannot agree on every ray; there the agreement is counted, not required to be total."""
+    fl = flats['teapot']
+    pt = P.PathTracer(64, 64, device=0, flags=0 if lds else P.PT_FLAG_NO_LDS_SCENE)
+    pt.upload_scene(fl['v'], fl['n'], fl['mat_idx'], fl['materials'])
+    assert pt.stats().sceneInLds == (1 if lds else 0)
+    o = oracle_py.Oracle(fl, build_tree=False)
+    rng = np.random.default_rng(8)
+    n = 20000
+    centre = np.array([1.0, 0.0, 7.0]); extent = 17.0
+    for far in (1e2, 1e3, 1e4):
+        dirs = rng.normal(size=(n, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        org = centre - dirs * extent * far + rng.normal(size=(n, 3)) * extent * 0.3
+        target = centre + rng.uniform(-0.5, 0.5, size=(n, 3)) * extent
+        d = target - org; d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = np.concatenate([org, d], axis=1).astype(np.float32)
+        tri, t, u, v, _ = pt.trace(rays)
+        otri, ot, ou, ov = o.trace_rays(rays, kind=0)
+        free = pt.hitsNothing(rays); ofree = o.trace_rays(rays, kind=1)[0] < 0
+        assert (otri >= 0).mean() > 0.5
+        if far <= 1e3:
+            assert np.array_equal(tri, otri)
+            hit = otri >= 0
+            assert np.array_equal(t[hit].view(np.uint32), ot[hit].view(np.uint32))
+            assert np.array_equal(free, ofree)
+        else:
+            assert (tri != otri).mean() < 1e-3 and (free != ofree).mean() < 1e-3
