@@ -369,7 +369,9 @@ void ensureWavefront(PtHandle* h) {
   h->bSlotQ.alloc((uint64_t)capSlots * 16);
   uint64_t capHit = capQueue + (uint64_t)PT_SEGS * PT_HIT_SLACK;
   h->bHitA.alloc(capHit * 16); h->bHitB.alloc(capHit * 16);
-  h->bRayO.alloc(NI ? capQueue * 16 : 16); h->bRayD.alloc(NI ? capQueue * 16 : 16);      // indirect rays only
+  // indirect rays only; as large as the hit arrays, so that the fused shading can use the two pairs alternately as the
+  // hit queues of successive bounce rounds (kernels.h: Wavefront::hitOutA)
+  h->bRayO.alloc(NI ? capHit * 16 : 16); h->bRayD.alloc(NI ? capHit * 16 : 16);
   h->bLacc.alloc((uint64_t)lanes * capSlots * 16);
   // chain records are recognised by the tag of the batch that wrote them: fresh memory must not hold one by chance
   HIPCHECK(hipMemset(h->bLacc.p, 0, (uint64_t)lanes * capSlots * 16));
@@ -399,6 +401,7 @@ void ensureWavefront(PtHandle* h) {
   w.shO = h->bShO.as<float4>(); w.shD = h->bShD.as<float4>(); w.shW = h->bShW.as<float4>(); w.shX = h->bShX.as<float4>();
   w.stats = h->bStats.as<unsigned long long>();
   w.capSlots = capSlots; w.capQueue = (uint32_t)capQueue; w.capHit = (uint32_t)capHit; w.lanes = lanes;
+  w.rayCap = NI ? (uint32_t)capHit : 0u; w.hitOutA = w.hitOutB = nullptr; w.fuse = 0; w.chainMask = 0;
   h->wfKinds = kinds; h->wfRounds = rounds;
 }
 
@@ -421,10 +424,27 @@ struct WfState { Wavefront wf; const QMeta* hostMetas; const QMeta* devMetas; Vi
 // Tags of the batches of this process (Wavefront::tag): never zero, never repeated while a record could still hold one.
 std::atomic<uint32_t> g_batchTag{0};
 
+// Whether this batch runs the shading variant that traces the rays it spawns (kernels.h: Wavefront::fuse): scene and
+// shading tables small enough to share a shade workgroup's LDS, something to fuse (indirect chains, or sun / sky rays
+// that no light-group kernel has to run ahead of), and, for the chains, ray arrays as large as the hit arrays.
+uint32_t fuseBits(const PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, const Wavefront& wf) {
+  if (h->cfg.flags & PT_FLAG_NO_FUSE) return 0;
+  if (lc.countVisits) return 0;                       // visits are counted by the traversal kernels proper
+  const uint32_t tables = shadeTableBytes(h->dsc);
+  if (!h->dsc.ldsBytes || !tables || h->dsc.ldsBytes + tables > PT_FUSE_LDS_BYTES) return 0;
+  const bool chains = dc.mode == 1 && dc.numIndirect > 0;
+  const bool env = dc.hasSky && !(dc.hasLights && h->dsc.numLightGroups);
+  if (chains && wf.rayCap < wf.capHit) return 0;
+  if (!chains && !env) return 0;
+  return 1u | (env ? 2u : 0u);
+}
+
 void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, const WfState& ws) {
   Wavefront wf = ws.wf;
   do { wf.tag = ++g_batchTag; } while (wf.tag == 0);
   wf.divCap = makeFastDiv(wf.capSlots); wf.round = 0;
+  wf.fuse = fuseBits(h, dc, lc, wf);
+  wf.chainMask = wf.fuse && dc.mode == 1 && dc.numIndirect <= 8 && h->dsc.numMats < 0xFFFFFFu ? 1u : 0u;
   const uint32_t perStage = 2 + PT_MAX_KINDS;
   const int kinds = (int)((dc.hasLights ? h->dsc.numLightGroups : 0) + (dc.hasSky ? 1 : 0));
   const QMeta* desc = ws.devMetas;
@@ -449,14 +469,45 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
     scan((size_t)s * perStage + 1, 1 + kinds);
     launchShadowKinds(h, lc, dc, wf, primary);
   };
+  // Fused shading: the shade of stage s reads the hit queue of stage s and appends the hits of the rays it traced to the
+  // hit queue of stage s + 1, whose records lie in the other pair of arrays (odd stages: hitA/hitB, even: rayO/rayD).
+  float4* const pairA[2] = {ws.wf.rayO, ws.wf.hitA};
+  float4* const pairB[2] = {ws.wf.rayD, ws.wf.hitB};
+  auto fusedStage = [&](uint32_t s, bool primary, bool last) {
+    bind(s);
+    wf.round = primary ? 0u : s - 2u;
+    wf.hitA = pairA[s & 1u]; wf.hitB = pairB[s & 1u];
+    wf.hitOutA = pairA[(s + 1u) & 1u]; wf.hitOutB = pairB[(s + 1u) & 1u];
+    // continuation rays exist in mode 1 only (mode 0 has two stages of queue descriptors and nothing to append)
+    if (dc.mode == 1) wf.rayOut = ws.hostMetas[(size_t)(s + 1) * perStage];              // the hit queue of the next stage
+    if (primary) {
+      Timed t(h, PT_K_EXTEND); launchExtend(lc, h->dsc, dc, pm, h->acc, wf, true); t.done();
+      scan((size_t)s * perStage, 1);
+    }
+    { Timed t(h, PT_K_SHADE); launchShade(lc, h->dsc, dc, pm, h->acc, wf, primary); t.done(); }
+    const bool shadows = kinds && !(wf.fuse & 2u);
+    const bool next = dc.mode == 1 && !last;
+    // the shadow queues of this stage and the hit queue of the next are PT_MAX_KINDS + 1 consecutive queues (unused
+    // kinds stay empty); one launch scans them all
+    if (shadows && next) scan((size_t)s * perStage + 2, PT_MAX_KINDS + 1);
+    else if (shadows) scan((size_t)s * perStage + 2, kinds);
+    else if (next) scan((size_t)(s + 1) * perStage, 1);
+    if (shadows) launchShadowKinds(h, lc, dc, wf, primary);
+  };
   uint32_t nslots = pm.npix * pm.k;
   wf.rayOut = ws.hostMetas[1];
   { Timed t(h, PT_K_OTHER); launchRaygen(lc, h->box, ws.masks, dc, pm, h->acc, nslots, wf); t.done(); }
   scan(1, 1);
-  stage(1, true);
   h->st.raysPrimary += nslots; h->st.samples += nslots;
-  if (dc.mode == 1)      // depth 0..maxDepth can still spawn a ray (the check is depth > maxDepth, rendering.d:380)
-    for (uint32_t round = 0; round <= dc.maxDepth; round++) stage(round + 2, false);
+  if (wf.fuse) {
+    fusedStage(1, true, false);
+    if (dc.mode == 1)
+      for (uint32_t round = 0; round <= dc.maxDepth; round++) fusedStage(round + 2, false, round == dc.maxDepth);
+  } else {
+    stage(1, true);
+    if (dc.mode == 1)      // depth 0..maxDepth can still spawn a ray (the check is depth > maxDepth, rendering.d:380)
+      for (uint32_t round = 0; round <= dc.maxDepth; round++) stage(round + 2, false);
+  }
   { Timed t(h, PT_K_ACCUM); launchAccumulate(lc, ws.masks, dc, pm, h->acc, wf, h->dsc); t.done(); }
   HIPCHECK(hipGetLastError());
 }
@@ -1174,6 +1225,7 @@ int ptgpu_get_stats(PtHandle* h, PtStats* out) {
     h->st.nodesClosest = s[STAT_NODES_CLOSEST]; h->st.trisClosest = s[STAT_TRIS_CLOSEST];
     h->st.nodesAny = s[STAT_NODES_ANY]; h->st.trisAny = s[STAT_TRIS_ANY]; h->st.raysCulled = s[STAT_RAYS_CULLED];
     h->st.hits = s[STAT_HITS]; h->st.envEntries = s[STAT_ENV_ENTRIES];
+    h->st.hitsPrimary = s[STAT_HITS_PRIMARY]; h->st.raysIndirectInShade = s[STAT_FUSED_INDIRECT]; h->st.raysOcclusionInShade = s[STAT_FUSED_OCCL];
     *out = h->st;
   });
 }

@@ -797,6 +797,10 @@ __global__ void PT_TRAVERSAL_BOUNDS k_occluded(DevScene sc, float eps, V3 sunRad
 // ------------------------------------------------------------------------------------------------ shade
 struct ShadeCtx {
   const DevScene& sc; const DevCfg& cfg; const Wavefront& wf; uint32_t* sCnt; uint32_t T, segCapRay, segCapSh;
+  // FUSE (rays traced where they are made, see k_shade): segment size of the hit queue the continuation rays' hits go
+  // to, whether the sun and sky rays are traced here too, and what the lane traced (indirect rays, sun/sky rays,
+  // vertices with a sun or sky ray)
+  uint32_t segCapHit = 0; bool fuseEnv = false; uint32_t nInd = 0, nOccl = 0, nEnv = 0;
 };
 
 // One computeLindirect head (rendering.d:378-385): Russian roulette, direction, ray; appended to ray queue qOut.
@@ -804,8 +808,8 @@ struct ShadeCtx {
 // depth (1) and generator state (the chain's stream after these three draws) follow from the lane slot and that
 // material, so they are not stored: the ray carries firstMat in the free word of its direction record and the shading
 // of its hit works them out again (most such rays hit nothing and nobody would read what was stored).
-template <bool FIRST>
-__device__ __forceinline__ void bounce(ShadeCtx& cx, bool active, Rng& g, uint32_t depth, V3 T, V3 color, V3 pos, V3 normal,
+template <bool FIRST, bool FUSE>
+__device__ __forceinline__ bool bounce(ShadeCtx& cx, bool active, Rng& g, uint32_t depth, V3 T, V3 color, V3 pos, V3 normal,
                                        uint32_t laneSlot, uint32_t firstMat) {
   bool alive = false; V3 dir = v3(0, 0, 0);
   if (active) {
@@ -817,16 +821,39 @@ __device__ __forceinline__ void bounce(ShadeCtx& cx, bool active, Rng& g, uint32
       alive = true;
     }
   }
-  uint32_t idx = waveAppend(alive, &cx.sCnt[0]);
-  if (alive) {
-    uint32_t e = cx.T * cx.segCapRay + idx;
-    cx.wf.rayO[e] = f4(pos + normal * 0.1f, u2f(laneSlot));
-    cx.wf.rayD[e] = f4(dir, FIRST ? u2f(firstMat) : 0.0f);
-    if (!FIRST) {
-      // BRDF * PI * color == color: the factor the caller multiplies computeLrefl with (rendering.d:391)
-      cx.wf.thr[laneSlot] = f4(T * color, u2f(depth + 1));
-      cx.wf.rng[laneSlot] = make_uint2(g.s0, g.s1);
+  if constexpr (FUSE) {
+    // the ray is traced here (Scene.trace, rendering.d:389) and what is appended is its hit, in the form extend writes
+    bool isHit = false; Hit h; h.t = 0; h.u = 0; h.v = 0; h.tri = 0;
+    const V3 o = pos + normal * 0.1f;
+    if (alive) {
+      uint32_t cN = 0, cT = 0;
+      isHit = traverse<false, true, false>(cx.sc, o, dir, cx.cfg.eps, h, cN, cT);
+      cx.nInd++;
     }
+    uint32_t idx = waveAppend(isHit, &cx.sCnt[0]);
+    if (isHit) {
+      uint32_t e = cx.T * cx.segCapHit + idx;
+      cx.wf.hitOutA[e] = f4(o + dir * h.t, u2f(h.tri));
+      cx.wf.hitOutB[e] = make_float4(h.u, h.v, u2f(laneSlot), FIRST ? u2f(firstMat) : 0.0f);
+      if (!FIRST) {
+        cx.wf.thr[laneSlot] = f4(T * color, u2f(depth + 1));
+        cx.wf.rng[laneSlot] = make_uint2(g.s0, g.s1);
+      }
+    }
+    return isHit;
+  } else {
+    uint32_t idx = waveAppend(alive, &cx.sCnt[0]);
+    if (alive) {
+      uint32_t e = cx.T * cx.segCapRay + idx;
+      cx.wf.rayO[e] = f4(pos + normal * 0.1f, u2f(laneSlot));
+      cx.wf.rayD[e] = f4(dir, FIRST ? u2f(firstMat) : 0.0f);
+      if (!FIRST) {
+        // BRDF * PI * color == color: the factor the caller multiplies computeLrefl with (rendering.d:391)
+        cx.wf.thr[laneSlot] = f4(T * color, u2f(depth + 1));
+        cx.wf.rng[laneSlot] = make_uint2(g.s0, g.s1);
+      }
+    }
+    return alive;
   }
 }
 
@@ -843,9 +870,9 @@ __device__ __forceinline__ void emitShadow(ShadeCtx& cx, int kind, bool emit, V3
 // computeLdirect up to (not including) the trace calls, rendering.d:396-462: emits one shadow ray per light group and
 // one entry for the sun and sky rays together (envX: what the kernel that traces them needs besides, see k_occluded).
 // Returns whether the lane emitted that entry.
-template <bool LDST>
+template <bool LDST, bool FUSE>
 __device__ __forceinline__ bool directLight(ShadeCtx& cx, const ShadeTables<LDST>& tb, bool active, Rng& g, V3 x, V3 normalX, V3 Tw, float4 envX,
-                                            uint32_t laneSlot) {
+                                            uint32_t laneSlot, bool direct) {
   const DevScene& sc = cx.sc; const DevCfg& cfg = cx.cfg;
   float eps = cfg.eps;
   int kind = 0;
@@ -893,6 +920,27 @@ __device__ __forceinline__ bool directLight(ShadeCtx& cx, const ShadeTables<LDST
       eSky = sSky > eps;
     }
     emitted = eSun || eSky;
+    if constexpr (FUSE) {
+      if (cx.fuseEnv) {
+        // Scene.hitsNothing of both rays and the `L += ...` that follows (rendering.d:440-443, 455-457) right here: the body
+        // of k_occluded for this vertex, same operations in the same order
+        if (emitted) {
+          const V3 org = x + normalX * 0.1f;
+          bool vSun = false, vSky = false;
+          Hit h; uint32_t cN = 0, cT = 0;
+          if (eSun) vSun = !traverse<true, true, false, true>(sc, org, dSun, eps, h, cN, cT);
+          if (eSky) vSky = !traverse<true, true, false>(sc, org, dSky, eps, h, cN, cT);
+          cx.nOccl += (eSun ? 1u : 0u) + (eSky ? 1u : 0u); cx.nEnv++;
+          if (direct || vSun || vSky) {
+            float4 L = direct ? make_float4(0.0f, 0.0f, 0.0f, envX.w) : loadLacc(cx.wf.Lacc, laneSlot, cx.wf.capSlots, cx.wf.tag);
+            if (vSun) { V3 c = Tw * cfg.sunRadiance * sSun; L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; }
+            if (vSky) { V3 c = Tw * cfg.skyRadiance * sSky; L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; }
+            cx.wf.Lacc[laneSlot] = L;
+          }
+        }
+        return emitted;
+      }
+    }
     uint32_t idx = waveAppend(emitted, &cx.sCnt[1 + kind]);
     if (emitted) {
       size_t ex = cx.T * cx.segCapSh + idx, e = (size_t)kind * cx.wf.capQueue + ex;
@@ -912,22 +960,36 @@ __device__ __forceinline__ bool directLight(ShadeCtx& cx, const ShadeTables<LDST
 // !PRIMARY: the part of computeLindirect after its trace has hit (rendering.d:390-391) = computeLrefl at the hit.
 // Block-task T = blockIdx.x reads flat entries [T*P, (T+1)*P) of the hit queue and fills segment T of the
 // output queues.
-template <bool PRIMARY, bool LDST>
+// FUSE (scenes small enough for every shade workgroup to hold nodes and triangles in LDS beside its tables): the rays a
+// vertex spawns are traced right here instead of being queued -- the continuation ray of a chain (what is appended
+// is its hit, to the next stage's hit queue: no ray queue, no extend launch for indirect rays) and, when no
+// light-group kernel adds to L in between, the sun and sky rays (no queue entry, no k_occluded launch).  Same device
+// functions, same operations per ray; what disappears is 64 B of queue traffic per indirect ray and 80 B per sun/sky
+// entry -- on a 12-triangle scene that traffic is what the launches wait for.  PRIMARY: a chain whose first ray hit
+// something is noted in the top bits of the view-ray record's tag word (wf.chainMask), so that accumulate reads only
+// the chain records that can hold anything.
+template <bool PRIMARY, bool LDST, bool FUSE>
 __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, Wavefront wf,
                                                int numKinds) {
+  static_assert(!FUSE || LDST, "the fused variant keeps scene and tables in LDS");
   __shared__ uint32_t sCnt[1 + PT_MAX_KINDS];
   if (threadIdx.x <= PT_MAX_KINDS) sCnt[threadIdx.x] = 0;
-  const ShadeTables<LDST> tb{sc, 0};
+  if constexpr (FUSE) stageScene<true>(sc);
+  const ShadeTables<LDST> tb{sc, FUSE ? 2 * sc.numNodes + 3 * sc.numTris : 0};
   tb.stage();
   __syncthreads();
   uint32_t T = blockIdx.x;
   uint32_t segCap = wf.capQueue / PT_SEGS;
   ShadeCtx cx{sc, cfg, wf, sCnt, T, segCap, segCap};
+  cx.segCapHit = wf.capHit / PT_SEGS; cx.fuseEnv = FUSE && (wf.fuse & 2u);
   const bool direct = envDirect(cfg, sc, PRIMARY);
   Task tk = taskOf(wf.hitQ, T);
   SegCursor seg = segCursor(wf.hitQ, tk.seg);
   const FastDiv divCap = wf.divCap;
-  if (T == 0 && threadIdx.x == 0) atomicAdd(&wf.stats[STAT_HITS], (unsigned long long)wf.hitQ.prefix[PT_SEGS]);
+  if (T == 0 && threadIdx.x == 0) {
+    atomicAdd(&wf.stats[STAT_HITS], (unsigned long long)wf.hitQ.prefix[PT_SEGS]);
+    if (PRIMARY) atomicAdd(&wf.stats[STAT_HITS_PRIMARY], (unsigned long long)wf.hitQ.prefix[PT_SEGS]);
+  }
   for (uint32_t base = tk.begin; base < tk.end; base += blockDim.x) {
     uint32_t j = base + threadIdx.x;
     bool active = j < tk.end;
@@ -966,22 +1028,33 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg 
       color = v3(m.y, m.z, m.w);
       matTag = f2u(q0.w) + 1u;
     }
-    V3 Tw = Tp * (PT_BRDF * color);
-    bool env = directLight(cx, tb, active, g, hitPos, normal, Tw, direct ? f4(color, u2f(matTag)) : f4(Tw, 0.0f), laneSlot);
-    // `vec3 L;` of computeLdirect (rendering.d:399) + the tag; when the sun / sky entry carries it, the kernel that
-    // traces them stores L
-    if (PRIMARY && active && !(direct && env)) wf.Lacc[laneSlot] = make_float4(0.0f, 0.0f, 0.0f, u2f(matTag));
-    if (cfg.mode == 1) {
-      if (PRIMARY) {
-        for (uint32_t c = 0; c < cfg.numIndirect; c++) {               // the loop at rendering.d:474-476
-          uint32_t lane = (c + 1) * wf.capSlots + laneSlot;
-          Rng gc; gc.s0 = 1; gc.s1 = 0;
-          if (active) gc.seed(cfg.seed, gp, sampleIdx, c + 1);
-          bounce<true>(cx, active, gc, 0, v3(1, 1, 1), color, hitPos, normal, lane, matTag - 1u);
-        }
-      } else {
-        bounce<false>(cx, active, g, depth, Tp, color, hitPos, normal, laneSlot, 0u);
+    uint32_t tagWord = matTag;
+    if (PRIMARY && cfg.mode == 1) {
+      // the loop at rendering.d:474-476; every chain has a generator stream of its own, so its place in this kernel
+      // is free: ahead of computeLdirect, because the record that carries the tag word is written there
+      uint32_t hitMask = 0;
+      for (uint32_t c = 0; c < cfg.numIndirect; c++) {
+        uint32_t lane = (c + 1) * wf.capSlots + laneSlot;
+        Rng gc; gc.s0 = 1; gc.s1 = 0;
+        if (active) gc.seed(cfg.seed, gp, sampleIdx, c + 1);
+        if (bounce<true, FUSE>(cx, active, gc, 0, v3(1, 1, 1), color, hitPos, normal, lane, matTag - 1u)) hitMask |= 1u << c;
       }
+      if (FUSE && wf.chainMask) tagWord |= hitMask << 24;
+    }
+    V3 Tw = Tp * (PT_BRDF * color);
+    bool env = directLight<LDST, FUSE>(cx, tb, active, g, hitPos, normal, Tw, direct ? f4(color, u2f(tagWord)) : f4(Tw, 0.0f), laneSlot, direct);
+    // `vec3 L;` of computeLdirect (rendering.d:399) + the tag; when the sun / sky entry carries it, the code that
+    // traces them stores L
+    if (PRIMARY && active && !(direct && env)) wf.Lacc[laneSlot] = make_float4(0.0f, 0.0f, 0.0f, u2f(tagWord));
+    if (!PRIMARY && cfg.mode == 1) bounce<false, FUSE>(cx, active, g, depth, Tp, color, hitPos, normal, laneSlot, 0u);
+  }
+  if constexpr (FUSE) {
+    uint32_t nInd = cx.nInd, nOccl = cx.nOccl, nEnv = cx.nEnv;
+    for (int off = 32; off > 0; off >>= 1) { nInd += __shfl_down(nInd, off); nOccl += __shfl_down(nOccl, off); nEnv += __shfl_down(nEnv, off); }
+    if ((threadIdx.x & 63) == 0) {
+      if (nInd) { atomicAdd(&wf.stats[STAT_RAYS_INDIRECT], (unsigned long long)nInd); atomicAdd(&wf.stats[STAT_FUSED_INDIRECT], (unsigned long long)nInd); }
+      if (nOccl) { atomicAdd(&wf.stats[STAT_RAYS_OCCL], (unsigned long long)nOccl); atomicAdd(&wf.stats[STAT_FUSED_OCCL], (unsigned long long)nOccl); }
+      if (nEnv) atomicAdd(&wf.stats[STAT_ENV_ENTRIES], (unsigned long long)nEnv);
     }
   }
   __syncthreads();
@@ -1012,13 +1085,17 @@ __global__ void __launch_bounds__(256) k_accumulate(ViewMasks masks, DevCfg cfg,
     uint32_t slot = s * pm.npix + lp;
     float4 L = wf.Lacc[slot];
     V3 add = xyz(L);
-    const uint32_t tag = f2u(L.w);
-    if (tag) {
+    const uint32_t tagWord = f2u(L.w);
+    if (tagWord) {
+      // wf.chainMask: the low 24 bits are the tag, the bits above say which chains' first rays hit anything -- the
+      // record of a chain that did not was never added to, and adding its zero would not change the sum
+      const uint32_t tag = wf.chainMask ? tagWord & 0xFFFFFFu : tagWord, chains = wf.chainMask ? tagWord >> 24 : 0xFFFFFFFFu;
       float4 m = mats[tag - 1u];
       add = m.x * v3(m.y, m.z, m.w) + add;
       if (cfg.mode == 1) {
         V3 sum = v3(0, 0, 0);
         for (uint32_t c = 0; c < cfg.numIndirect; c++) {
+          if (!((chains >> (c & 31u)) & 1u)) continue;
           float4 Lc = wf.Lacc[(size_t)(c + 1) * wf.capSlots + slot];
           sum = sum + (f2u(Lc.w) == wf.tag ? xyz(Lc) : v3(0, 0, 0));          // nothing was added to a record of another batch
         }
@@ -1244,10 +1321,15 @@ void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, con
   int numKinds = (cfg.hasLights ? (int)sc.numLightGroups : 0) + (cfg.hasSky ? 1 : 0);
   const uint32_t lds = shadeTableBytes(sc);
   const dim3 grid(PT_SEGS), block(PT_SHADE_THREADS);
-  if (primary && lds) hipLaunchKernelGGL((k_shade<true, true>), grid, block, lds, lc.stream, sc, cfg, pm, acc, wf, numKinds);
-  else if (primary) hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
-  else if (lds) hipLaunchKernelGGL((k_shade<false, true>), grid, block, lds, lc.stream, sc, cfg, pm, acc, wf, numKinds);
-  else hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+  if (wf.fuse) {
+    const uint32_t all = lds + (uint32_t)sc.ldsBytes;
+    if (primary) hipLaunchKernelGGL((k_shade<true, true, true>), grid, block, all, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+    else hipLaunchKernelGGL((k_shade<false, true, true>), grid, block, all, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+  }
+  else if (primary && lds) hipLaunchKernelGGL((k_shade<true, true, false>), grid, block, lds, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+  else if (primary) hipLaunchKernelGGL((k_shade<true, false, false>), grid, block, 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+  else if (lds) hipLaunchKernelGGL((k_shade<false, true, false>), grid, block, lds, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+  else hipLaunchKernelGGL((k_shade<false, false, false>), grid, block, 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
 }
 
 void launchAccumulate(const LaunchCfg& lc, const ViewMasks& masks, const DevCfg& cfg, const PixMap& pm, float4* acc,

@@ -401,3 +401,35 @@ def test_repeated_small_passes_replayed_from_a_graph_equal_one_render(require_gp
         for _ in range(3):
             t.render_frame(1)
     assert np.array_equal(a.read_pixels()['sum'].view(np.uint32), b.read_pixels()['sum'].view(np.uint32))
+
+
+@pytest.mark.parametrize('name,sky,mode', [('chest1', 1, 0), ('chest1', 1, 1), ('cornell-box', 0, 1), ('cornell-box', 1, 1),
+                                           ('cornell-box', 1, 0)])
+def test_shading_that_traces_its_own_rays_equals_the_queued_path(require_gpu, name, sky, mode):
+    """Small scenes: the shading kernel traces the rays it spawns (continuation rays; sun and sky rays when no light
+    group has to be added first) instead of queueing them for extend / occluded.  Same rays, same arithmetic: the
+    accumulators are the same bits as with PT_FLAG_NO_FUSE, every counter is equal, and the counters say which path ran."""
+    W, H, spp = 96, 64, 12
+    out = {}
+    for flags in (0, P.PT_FLAG_NO_FUSE):
+        pt = make_tracer(name, W, H, has_sky=sky, mode=mode, seed=77, max_depth=4, flags=flags | P.PT_FLAG_TIME_KERNELS)
+        pt.render_frame(spp)
+        pt.render_frame(3)                                # a second batch: chain records of the first carry an older tag
+        st = pt.stats()
+        out[flags] = (pt.read_pixels(), st)
+        pt.close()
+    (a, sa), (b, sb) = out[0], out[P.PT_FLAG_NO_FUSE]
+    assert np.array_equal(a['n'], b['n']) and np.array_equal(a['sum'].view(np.uint32), b['sum'].view(np.uint32))
+    for f in ('raysPrimary', 'raysLight', 'raysIndirect', 'raysOcclusion', 'raysCulled', 'hits', 'envEntries', 'samples'):
+        assert getattr(sa, f) == getattr(sb, f), f
+    assert sb.raysIndirectInShade == 0 and sb.raysOcclusionInShade == 0
+    lights = name == 'cornell-box'
+    assert sa.raysIndirectInShade == sa.raysIndirect and (sa.raysIndirect > 0) == (mode == 1)
+    assert sa.raysOcclusionInShade == (0 if lights else sa.raysOcclusion)
+    if sky:
+        assert sa.raysOcclusion > 0
+    k = list(P.PT_K_NAMES)
+    assert sa.kernelLaunches[k.index('extend')] == 2      # the view rays of the two batches; indirect rays never get there
+    assert sb.kernelLaunches[k.index('extend')] == (2 if mode == 0 else 2 * (2 + 4))
+    if sky and not lights:
+        assert sa.kernelLaunches[k.index('occluded')] == 0 and sb.kernelLaunches[k.index('occluded')] > 0
