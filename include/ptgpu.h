@@ -74,8 +74,8 @@ typedef struct PtConfig {
                                      same arguments, scene, camera and configuration, and replayed from then on)     */
 #define PT_FLAG_NO_FUSE 128u      /* never trace rays inside the shading kernel (default: when nodes, triangles and shading
                                      tables together fit in 24 KB of LDS, shading traces the rays it spawns itself --
-                                     continuation rays of the indirect chains, and sun / sky rays when the scene has no
-                                     light groups -- instead of queueing them; same rays, same results)            */
+                                     light-sample rays, sun / sky rays, continuation rays of the indirect chains --
+                                     instead of queueing them; same rays, same results)                            */
 
 typedef struct PtMaterial { float emissive; float color[3]; } PtMaterial;        /* rendering.d:33-37 */
 typedef struct PtPixel { float color[3]; float n; float sum[3]; } PtPixel;        /* rendering.d:24-30 */
@@ -96,8 +96,9 @@ typedef struct PtStats {
   uint64_t hits;             /* Scene.trace calls of computeL / computeLindirect that hit: vertices shaded     */
   uint64_t envEntries;       /* shaded vertices that trace a sun ray, a sky ray or both (one queue entry each) */
   uint64_t hitsPrimary;      /* of hits: view rays that hit                                                    */
-  uint64_t raysIndirectInShade;  /* of raysIndirect / raysOcclusion: rays the shading kernel traced itself instead   */
-  uint64_t raysOcclusionInShade; /* of queueing them for the traversal kernels (small scenes, see PT_FLAG_NO_FUSE) */
+  uint64_t raysLightInShade;     /* of raysLight / raysIndirect / raysOcclusion: rays the shading kernel traced itself */
+  uint64_t raysIndirectInShade;  /* instead of queueing them for the traversal kernels (small scenes, see              */
+  uint64_t raysOcclusionInShade; /* PT_FLAG_NO_FUSE)                                                                   */
   double kernelMs[PT_K_COUNT];          /* with PT_FLAG_TIME_KERNELS: summed event time per kernel kind   */
   uint64_t kernelLaunches[PT_K_COUNT];
   double renderMs;           /* event time first kernel -> last kernel of all ptgpu_render calls          */

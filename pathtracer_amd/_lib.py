@@ -26,7 +26,7 @@ class PtStats(C.Structure):
                 ('raysOcclusion', C.c_uint64), ('samples', C.c_uint64), ('nodesClosest', C.c_uint64),
                 ('trisClosest', C.c_uint64), ('nodesAny', C.c_uint64), ('trisAny', C.c_uint64), ('raysCulled', C.c_uint64),
                 ('hits', C.c_uint64), ('envEntries', C.c_uint64),
-                ('hitsPrimary', C.c_uint64), ('raysIndirectInShade', C.c_uint64), ('raysOcclusionInShade', C.c_uint64),
+                ('hitsPrimary', C.c_uint64), ('raysLightInShade', C.c_uint64), ('raysIndirectInShade', C.c_uint64), ('raysOcclusionInShade', C.c_uint64),
                 ('kernelMs', C.c_double * 6), ('kernelLaunches', C.c_uint64 * 6), ('renderMs', C.c_double),
                 ('numTriangles', C.c_uint32), ('numNodes', C.c_uint32), ('bvhDepth', C.c_uint32),
                 ('numLightGroups', C.c_uint32), ('sceneInLds', C.c_uint32), ('bvhOnGpu', C.c_uint32),

@@ -425,18 +425,16 @@ struct WfState { Wavefront wf; const QMeta* hostMetas; const QMeta* devMetas; Vi
 std::atomic<uint32_t> g_batchTag{0};
 
 // Whether this batch runs the shading variant that traces the rays it spawns (kernels.h: Wavefront::fuse): scene and
-// shading tables small enough to share a shade workgroup's LDS, something to fuse (indirect chains, or sun / sky rays
-// that no light-group kernel has to run ahead of), and, for the chains, ray arrays as large as the hit arrays.
+// shading tables small enough to share a shade workgroup's LDS and, for the chains, ray arrays as large as the hit arrays.
 uint32_t fuseBits(const PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, const Wavefront& wf) {
   if (h->cfg.flags & PT_FLAG_NO_FUSE) return 0;
   if (lc.countVisits) return 0;                       // visits are counted by the traversal kernels proper
   const uint32_t tables = shadeTableBytes(h->dsc);
   if (!h->dsc.ldsBytes || !tables || h->dsc.ldsBytes + tables > PT_FUSE_LDS_BYTES) return 0;
   const bool chains = dc.mode == 1 && dc.numIndirect > 0;
-  const bool env = dc.hasSky && !(dc.hasLights && h->dsc.numLightGroups);
   if (chains && wf.rayCap < wf.capHit) return 0;
-  if (!chains && !env) return 0;
-  return 1u | (env ? 2u : 0u);
+  if (!chains && !dc.hasSky && !(dc.hasLights && h->dsc.numLightGroups)) return 0;      // no ray is spawned at all
+  return 1u;
 }
 
 void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, const WfState& ws) {
@@ -485,14 +483,7 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
       scan((size_t)s * perStage, 1);
     }
     { Timed t(h, PT_K_SHADE); launchShade(lc, h->dsc, dc, pm, h->acc, wf, primary); t.done(); }
-    const bool shadows = kinds && !(wf.fuse & 2u);
-    const bool next = dc.mode == 1 && !last;
-    // the shadow queues of this stage and the hit queue of the next are PT_MAX_KINDS + 1 consecutive queues (unused
-    // kinds stay empty); one launch scans them all
-    if (shadows && next) scan((size_t)s * perStage + 2, PT_MAX_KINDS + 1);
-    else if (shadows) scan((size_t)s * perStage + 2, kinds);
-    else if (next) scan((size_t)(s + 1) * perStage, 1);
-    if (shadows) launchShadowKinds(h, lc, dc, wf, primary);
+    if (dc.mode == 1 && !last) scan((size_t)(s + 1) * perStage, 1);
   };
   uint32_t nslots = pm.npix * pm.k;
   wf.rayOut = ws.hostMetas[1];
@@ -1225,7 +1216,7 @@ int ptgpu_get_stats(PtHandle* h, PtStats* out) {
     h->st.nodesClosest = s[STAT_NODES_CLOSEST]; h->st.trisClosest = s[STAT_TRIS_CLOSEST];
     h->st.nodesAny = s[STAT_NODES_ANY]; h->st.trisAny = s[STAT_TRIS_ANY]; h->st.raysCulled = s[STAT_RAYS_CULLED];
     h->st.hits = s[STAT_HITS]; h->st.envEntries = s[STAT_ENV_ENTRIES];
-    h->st.hitsPrimary = s[STAT_HITS_PRIMARY]; h->st.raysIndirectInShade = s[STAT_FUSED_INDIRECT]; h->st.raysOcclusionInShade = s[STAT_FUSED_OCCL];
+    h->st.hitsPrimary = s[STAT_HITS_PRIMARY]; h->st.raysLightInShade = s[STAT_FUSED_LIGHT]; h->st.raysIndirectInShade = s[STAT_FUSED_INDIRECT]; h->st.raysOcclusionInShade = s[STAT_FUSED_OCCL];
     *out = h->st;
   });
 }

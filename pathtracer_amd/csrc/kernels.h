@@ -151,8 +151,8 @@ struct Wavefront {
                               // the five chain records of every shaded view-ray hit (most are never added to)
   FastDiv divCap;             // division by capSlots
   uint32_t round;             // bounce round of the stage being launched (0 = hits of the rays the view-ray hits spawned)
-  // Shading that traces the rays it spawns (k_shade<.., FUSE>; fuse bit 0: continuation rays, bit 1: sun and sky rays
-  // too).  The hits of a stage's continuation rays go to (hitOutA, hitOutB), the next stage's hit queue; the host
+  // Shading that traces the rays it spawns (k_shade<.., FUSE>, fuse != 0).  The hits of a stage's continuation rays go
+  // to (hitOutA, hitOutB), the next stage's hit queue; the host
   // alternates the two record arrays (hitA/hitB and rayO/rayD, both rayCap >= capHit entries then) between stages.
   float4* hitOutA; float4* hitOutB;
   uint32_t rayCap;            // entries of rayO / rayD
@@ -164,7 +164,7 @@ struct Wavefront {
 constexpr uint32_t PT_FUSE_LDS_BYTES = 24 * 1024;
 
 enum { STAT_RAYS_LIGHT = 0, STAT_RAYS_INDIRECT, STAT_RAYS_OCCL, STAT_NODES_CLOSEST, STAT_TRIS_CLOSEST,
-       STAT_NODES_ANY, STAT_TRIS_ANY, STAT_RAYS_CULLED, STAT_HITS, STAT_ENV_ENTRIES, STAT_FUSED_INDIRECT, STAT_FUSED_OCCL, STAT_HITS_PRIMARY,
+       STAT_NODES_ANY, STAT_TRIS_ANY, STAT_RAYS_CULLED, STAT_HITS, STAT_ENV_ENTRIES, STAT_FUSED_INDIRECT, STAT_FUSED_OCCL, STAT_HITS_PRIMARY, STAT_FUSED_LIGHT,
        STAT_COUNT };
 
 // Workgroups of a traversal kernel per CU when the scene copy in LDS takes `bytes` (0: it does not fit at all).

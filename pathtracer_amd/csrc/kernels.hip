@@ -142,6 +142,18 @@ struct Hit { float t, u, v; uint32_t tri; bool front; };
 #ifndef PT_SHADE_THREADS
 #define PT_SHADE_THREADS 256
 #endif
+// The shading variant that traces its own rays is bound by vector instructions, not by its stores: it wants more
+// waves per SIMD than 1024 block-tasks of 256 threads give (4).
+#ifndef PT_FUSE_THREADS
+#define PT_FUSE_THREADS 512
+#endif
+// Its traversals use the general box test, not the per-octant variants (17 more copies of the loop in one kernel).
+#ifndef PT_FUSE_WAVES
+#define PT_FUSE_WAVES 6
+#endif
+#ifndef PT_FUSE_OCTANTS
+#define PT_FUSE_OCTANTS false
+#endif
 #if defined(PT_STAMP) || defined(PT_SLOTS)
 #define PT_STAMP_ON 1
 #else
@@ -798,9 +810,8 @@ __global__ void PT_TRAVERSAL_BOUNDS k_occluded(DevScene sc, float eps, V3 sunRad
 struct ShadeCtx {
   const DevScene& sc; const DevCfg& cfg; const Wavefront& wf; uint32_t* sCnt; uint32_t T, segCapRay, segCapSh;
   // FUSE (rays traced where they are made, see k_shade): segment size of the hit queue the continuation rays' hits go
-  // to, whether the sun and sky rays are traced here too, and what the lane traced (indirect rays, sun/sky rays,
-  // vertices with a sun or sky ray)
-  uint32_t segCapHit = 0; bool fuseEnv = false; uint32_t nInd = 0, nOccl = 0, nEnv = 0;
+  // to, and what the lane traced (indirect rays, light-sample rays, sun/sky rays, vertices with a sun or sky ray)
+  uint32_t segCapHit = 0; uint32_t nInd = 0, nLight = 0, nOccl = 0, nEnv = 0;
 };
 
 // One computeLindirect head (rendering.d:378-385): Russian roulette, direction, ray; appended to ray queue qOut.
@@ -827,7 +838,9 @@ __device__ __forceinline__ bool bounce(ShadeCtx& cx, bool active, Rng& g, uint32
     const V3 o = pos + normal * 0.1f;
     if (alive) {
       uint32_t cN = 0, cT = 0;
-      isHit = traverse<false, true, false>(cx.sc, o, dir, cx.cfg.eps, h, cN, cT);
+#ifndef PT_PROBE_A
+      isHit = traverse<false, true, false, PT_FUSE_OCTANTS>(cx.sc, o, dir, cx.cfg.eps, h, cN, cT);
+#endif
       cx.nInd++;
     }
     uint32_t idx = waveAppend(isHit, &cx.sCnt[0]);
@@ -867,92 +880,138 @@ __device__ __forceinline__ void emitShadow(ShadeCtx& cx, int kind, bool emit, V3
   }
 }
 
+// pickRandomLightPoint (rendering.d:164-193) for light group li and the direction to the sample (rendering.d:404-412);
+// returns whether a ray is to be traced towards it.
+template <bool LDST>
+__device__ __forceinline__ bool sampleLight(const ShadeTables<LDST>& tb, Rng& g, uint32_t li, V3 x, V3 normalX, float eps, V3& phi,
+                                            float& lightDistance, float& ndot) {
+  uint32_t first = tb.lightFirst(li), cnt = tb.lightCount(li);
+  float a = g.uniform(0.0f, 1.0f);
+  uint32_t chosen = cnt - 1;
+  for (uint32_t j = 0; j < cnt; j++) {
+    float prob = tb.light(first + j, 10);
+    if (prob > a) { chosen = j; break; }
+    a -= prob;
+  }
+  uint32_t lt = first + chosen;
+  float u, v;
+  do { u = g.uniform(0.0f, 1.0f); v = g.uniform(0.0f, 1.0f); } while (!(u + v <= 1.0f));
+  V3 y = v3(tb.light(lt, 0), tb.light(lt, 1), tb.light(lt, 2)) + v3(tb.light(lt, 3), tb.light(lt, 4), tb.light(lt, 5)) * v +
+         v3(tb.light(lt, 6), tb.light(lt, 7), tb.light(lt, 8)) * u;
+  lightDistance = length(y - x);
+  phi = normalized(y - x);
+  ndot = dot(normalX, phi);
+  return ndot > eps;
+}
+
+// The sun direction (rendering.d:432-439) and the sky direction (rendering.d:448-454) sampled at a vertex, each with
+// whether its ray is traced and the cosine its radiance is weighted with.
+struct EnvSample { bool eSun, eSky; V3 dSun, dSky; float sSun, sSky; };
+__device__ __forceinline__ EnvSample sampleEnv(const DevCfg& cfg, Rng& g, V3 normalX) {
+  EnvSample s;
+  float psi = g.uniform(0.0f, 2.0f * PT_PI_F);
+  float phi = g.uniform(PT_PI_2_F - PT_PI_2_F * 0.01f, PT_PI_2_F);
+  s.dSun = angleToDirection(phi, psi, cfg.sunDir);
+  s.eSun = dot(normalX, s.dSun) > cfg.eps;
+  s.sSun = dot(normalX, cfg.sunDir);
+  psi = g.uniform(0.0f, 2.0f * PT_PI_F);
+  phi = g.uniform(0.0f, PT_PI_2_F);
+  s.dSky = angleToLocalDirection(phi, psi);
+  s.sSky = dot(normalX, s.dSky);
+  s.eSky = s.sSky > cfg.eps;
+  return s;
+}
+
 // computeLdirect up to (not including) the trace calls, rendering.d:396-462: emits one shadow ray per light group and
 // one entry for the sun and sky rays together (envX: what the kernel that traces them needs besides, see k_occluded).
 // Returns whether the lane emitted that entry.
-template <bool LDST, bool FUSE>
+template <bool LDST>
 __device__ __forceinline__ bool directLight(ShadeCtx& cx, const ShadeTables<LDST>& tb, bool active, Rng& g, V3 x, V3 normalX, V3 Tw, float4 envX,
-                                            uint32_t laneSlot, bool direct) {
+                                            uint32_t laneSlot) {
   const DevScene& sc = cx.sc; const DevCfg& cfg = cx.cfg;
   float eps = cfg.eps;
   int kind = 0;
   if (cfg.hasLights) {
     for (uint32_t li = 0; li < sc.numLightGroups; li++, kind++) {
       bool emit = false; V3 phi = v3(0, 0, 0); float lightDistance = 0.0f, ndot = 0.0f;
-      if (active) {
-        // pickRandomLightPoint, rendering.d:164-193
-        uint32_t first = tb.lightFirst(li), cnt = tb.lightCount(li);
-        float a = g.uniform(0.0f, 1.0f);
-        uint32_t chosen = cnt - 1;
-        for (uint32_t j = 0; j < cnt; j++) {
-          float prob = tb.light(first + j, 10);
-          if (prob > a) { chosen = j; break; }
-          a -= prob;
-        }
-        uint32_t lt = first + chosen;
-        float u, v;
-        do { u = g.uniform(0.0f, 1.0f); v = g.uniform(0.0f, 1.0f); } while (!(u + v <= 1.0f));
-        V3 y = v3(tb.light(lt, 0), tb.light(lt, 1), tb.light(lt, 2)) + v3(tb.light(lt, 3), tb.light(lt, 4), tb.light(lt, 5)) * v +
-               v3(tb.light(lt, 6), tb.light(lt, 7), tb.light(lt, 8)) * u;
-        lightDistance = length(y - x);
-        phi = normalized(y - x);
-        ndot = dot(normalX, phi);
-        emit = ndot > eps;
-      }
+      if (active) emit = sampleLight(tb, g, li, x, normalX, eps, phi, lightDistance, ndot);
       emitShadow(cx, kind, emit, x + normalX * eps, phi, lightDistance, Tw, ndot, laneSlot);
     }
   }
   bool emitted = false;
   if (cfg.hasSky) {
-    // sun (rendering.d:432-445) and sky (rendering.d:448-459) leave from the same point: one entry carries both
-    // directions, each with the cosine its radiance is weighted with; a direction that is not traced is stored as 0
-    bool eSun = false, eSky = false; V3 dSun = v3(0, 0, 0), dSky = v3(0, 0, 0); float sSun = 0.0f, sSky = 0.0f;
-    if (active) {
-      float psi = g.uniform(0.0f, 2.0f * PT_PI_F);
-      float phi = g.uniform(PT_PI_2_F - PT_PI_2_F * 0.01f, PT_PI_2_F);
-      dSun = angleToDirection(phi, psi, cfg.sunDir);
-      eSun = dot(normalX, dSun) > eps;
-      sSun = dot(normalX, cfg.sunDir);
-      psi = g.uniform(0.0f, 2.0f * PT_PI_F);
-      phi = g.uniform(0.0f, PT_PI_2_F);
-      dSky = angleToLocalDirection(phi, psi);
-      sSky = dot(normalX, dSky);
-      eSky = sSky > eps;
-    }
-    emitted = eSun || eSky;
-    if constexpr (FUSE) {
-      if (cx.fuseEnv) {
-        // Scene.hitsNothing of both rays and the `L += ...` that follows (rendering.d:440-443, 455-457) right here: the body
-        // of k_occluded for this vertex, same operations in the same order
-        if (emitted) {
-          const V3 org = x + normalX * 0.1f;
-          bool vSun = false, vSky = false;
-          Hit h; uint32_t cN = 0, cT = 0;
-          if (eSun) vSun = !traverse<true, true, false, true>(sc, org, dSun, eps, h, cN, cT);
-          if (eSky) vSky = !traverse<true, true, false>(sc, org, dSky, eps, h, cN, cT);
-          cx.nOccl += (eSun ? 1u : 0u) + (eSky ? 1u : 0u); cx.nEnv++;
-          if (direct || vSun || vSky) {
-            float4 L = direct ? make_float4(0.0f, 0.0f, 0.0f, envX.w) : loadLacc(cx.wf.Lacc, laneSlot, cx.wf.capSlots, cx.wf.tag);
-            if (vSun) { V3 c = Tw * cfg.sunRadiance * sSun; L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; }
-            if (vSky) { V3 c = Tw * cfg.skyRadiance * sSky; L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; }
-            cx.wf.Lacc[laneSlot] = L;
-          }
-        }
-        return emitted;
-      }
-    }
+    // sun and sky leave from the same point: one entry carries both directions, each with the cosine its radiance is
+    // weighted with; a direction that is not traced is stored as 0
+    EnvSample s; s.eSun = s.eSky = false; s.dSun = s.dSky = v3(0, 0, 0); s.sSun = s.sSky = 0.0f;
+    if (active) s = sampleEnv(cfg, g, normalX);
+    emitted = s.eSun || s.eSky;
     uint32_t idx = waveAppend(emitted, &cx.sCnt[1 + kind]);
     if (emitted) {
       size_t ex = cx.T * cx.segCapSh + idx, e = (size_t)kind * cx.wf.capQueue + ex;
-      if (!eSun) dSun = v3(0, 0, 0);
-      if (!eSky) dSky = v3(0, 0, 0);
+      if (!s.eSun) s.dSun = v3(0, 0, 0);
+      if (!s.eSky) s.dSky = v3(0, 0, 0);
       cx.wf.shO[e] = f4(x + normalX * 0.1f, u2f(laneSlot));
-      cx.wf.shD[e] = f4(dSun, sSun);
-      cx.wf.shW[e] = f4(dSky, sSky);
+      cx.wf.shD[e] = f4(s.dSun, s.sSun);
+      cx.wf.shW[e] = f4(s.dSky, s.sSky);
       cx.wf.shX[ex] = envX;
     }
   }
   return emitted;
+}
+
+// computeLdirect whole (rendering.d:396-462) for the shading variant that traces its own rays: every light group's
+// sample ray (the body of k_connect), then the sun and the sky ray (the body of k_occluded), each contribution added
+// to L in that order -- the order in which the queued kernels are launched.  fromZero: L is the `vec3 L` of a
+// view-ray hit, gathered from 0 and stored with the record's tag word in any case; otherwise L is the chain's record,
+// read when the first contribution arrives and written back if there was one.
+template <bool LDST>
+__device__ __forceinline__ void directLightTraced(ShadeCtx& cx, const ShadeTables<LDST>& tb, bool active, Rng& g, V3 x, V3 normalX, V3 Tw,
+                                                  uint32_t tagWord, bool fromZero, uint32_t laneSlot) {
+  const DevScene& sc = cx.sc; const DevCfg& cfg = cx.cfg;
+  const float eps = cfg.eps;
+  float4 L = make_float4(0.0f, 0.0f, 0.0f, u2f(tagWord));
+  bool have = fromZero, dirty = false;
+  auto add = [&](V3 c) {
+    if (!have) { L = loadLacc(cx.wf.Lacc, laneSlot, cx.wf.capSlots, cx.wf.tag); have = true; }
+    L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; dirty = true;
+  };
+  if (active) {
+    Hit h; uint32_t cN = 0, cT = 0;
+    if (cfg.hasLights) {
+      for (uint32_t li = 0; li < sc.numLightGroups; li++) {
+        V3 phi; float lightDistance, ndot;
+        if (sampleLight(tb, g, li, x, normalX, eps, phi, lightDistance, ndot)) {
+          cx.nLight++;
+          // Scene.trace + `if(distanceY > lightDistance - FloatEpsilon)`, rendering.d:414-425
+          if (traverse<false, true, false, PT_FUSE_OCTANTS>(sc, x + normalX * eps, phi, eps, h, cN, cT) && h.t > lightDistance - eps) {
+            float4 q0 = tb.nrm(3 * h.tri), q1 = tb.nrm(3 * h.tri + 1), q2 = tb.nrm(3 * h.tri + 2);
+            V3 normalY = interpNormal(xyz(q0), xyz(q1), xyz(q2), h.u, h.v);
+            float4 m = tb.mat(f2u(q0.w));
+            V3 Le = m.x * v3(m.y, m.z, m.w);
+            float G = ndot * dot(normalY, -phi) / (lightDistance * lightDistance);
+            if (!(G > 0.0f)) G = 0.0f;
+            add(Tw * Le * G * sc.lightArea[li]);
+          }
+        }
+      }
+    }
+    if (cfg.hasSky) {
+      const EnvSample s = sampleEnv(cfg, g, normalX);
+      if (s.eSun || s.eSky) {
+        // Scene.hitsNothing + `L += ...`, rendering.d:440-443 and 455-457
+        const V3 org = x + normalX * 0.1f;
+        bool vSun = false, vSky = false;
+#ifndef PT_PROBE_C
+        if (s.eSun) vSun = !traverse<true, true, false, PT_FUSE_OCTANTS>(sc, org, s.dSun, eps, h, cN, cT);
+        if (s.eSky) vSky = !traverse<true, true, false>(sc, org, s.dSky, eps, h, cN, cT);
+#endif
+        cx.nOccl += (s.eSun ? 1u : 0u) + (s.eSky ? 1u : 0u); cx.nEnv++;
+        if (vSun) add(Tw * cfg.sunRadiance * s.sSun);
+        if (vSky) add(Tw * cfg.skyRadiance * s.sSky);
+      }
+    }
+    if (fromZero || dirty) cx.wf.Lacc[laneSlot] = L;
+  }
 }
 
 // PRIMARY: the part of computeL after the view-ray trace has hit (rendering.d:472-477); the generator of
@@ -962,15 +1021,16 @@ __device__ __forceinline__ bool directLight(ShadeCtx& cx, const ShadeTables<LDST
 // output queues.
 // FUSE (scenes small enough for every shade workgroup to hold nodes and triangles in LDS beside its tables): the rays a
 // vertex spawns are traced right here instead of being queued -- the continuation ray of a chain (what is appended
-// is its hit, to the next stage's hit queue: no ray queue, no extend launch for indirect rays) and, when no
-// light-group kernel adds to L in between, the sun and sky rays (no queue entry, no k_occluded launch).  Same device
-// functions, same operations per ray; what disappears is 64 B of queue traffic per indirect ray and 80 B per sun/sky
-// entry -- on a 12-triangle scene that traffic is what the launches wait for.  PRIMARY: a chain whose first ray hit
+// is its hit, to the next stage's hit queue: no ray queue, no extend launch for indirect rays), the light-sample rays
+// and the sun and sky rays (no queue entries, no k_connect / k_occluded launches; L is gathered in registers in the
+// order those launches would have added to it).  Same device functions, same operations per ray; what disappears is
+// 64 B of queue traffic per indirect ray, 128 B per light-sample ray and 80 B per sun/sky entry -- on scenes of a few
+// dozen triangles that traffic is what the launches wait for.  PRIMARY: a chain whose first ray hit
 // something is noted in the top bits of the view-ray record's tag word (wf.chainMask), so that accumulate reads only
 // the chain records that can hold anything.
 template <bool PRIMARY, bool LDST, bool FUSE>
-__global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, Wavefront wf,
-                                               int numKinds) {
+__device__ __forceinline__ void shadeBody(const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* __restrict__ acc,
+                                          const Wavefront& wf, int numKinds) {
   static_assert(!FUSE || LDST, "the fused variant keeps scene and tables in LDS");
   __shared__ uint32_t sCnt[1 + PT_MAX_KINDS];
   if (threadIdx.x <= PT_MAX_KINDS) sCnt[threadIdx.x] = 0;
@@ -981,7 +1041,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg 
   uint32_t T = blockIdx.x;
   uint32_t segCap = wf.capQueue / PT_SEGS;
   ShadeCtx cx{sc, cfg, wf, sCnt, T, segCap, segCap};
-  cx.segCapHit = wf.capHit / PT_SEGS; cx.fuseEnv = FUSE && (wf.fuse & 2u);
+  cx.segCapHit = wf.capHit / PT_SEGS;
   const bool direct = envDirect(cfg, sc, PRIMARY);
   Task tk = taskOf(wf.hitQ, T);
   SegCursor seg = segCursor(wf.hitQ, tk.seg);
@@ -1029,29 +1089,43 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg 
       matTag = f2u(q0.w) + 1u;
     }
     uint32_t tagWord = matTag;
-    if (PRIMARY && cfg.mode == 1) {
-      // the loop at rendering.d:474-476; every chain has a generator stream of its own, so its place in this kernel
-      // is free: ahead of computeLdirect, because the record that carries the tag word is written there
+    // the loop at rendering.d:474-476; every chain has a generator stream of its own, so its place in this kernel is
+    // free: the traced variant runs it ahead of computeLdirect, because the record that carries the tag word (with
+    // the chains that hit) is written there
+    auto chainHeads = [&]() {
       uint32_t hitMask = 0;
+#ifdef PT_PROBE_B
+      for (uint32_t c = 0; c < 0; c++) {
+#else
       for (uint32_t c = 0; c < cfg.numIndirect; c++) {
+#endif
         uint32_t lane = (c + 1) * wf.capSlots + laneSlot;
         Rng gc; gc.s0 = 1; gc.s1 = 0;
         if (active) gc.seed(cfg.seed, gp, sampleIdx, c + 1);
         if (bounce<true, FUSE>(cx, active, gc, 0, v3(1, 1, 1), color, hitPos, normal, lane, matTag - 1u)) hitMask |= 1u << c;
       }
-      if (FUSE && wf.chainMask) tagWord |= hitMask << 24;
-    }
+      return hitMask;
+    };
     V3 Tw = Tp * (PT_BRDF * color);
-    bool env = directLight<LDST, FUSE>(cx, tb, active, g, hitPos, normal, Tw, direct ? f4(color, u2f(tagWord)) : f4(Tw, 0.0f), laneSlot, direct);
-    // `vec3 L;` of computeLdirect (rendering.d:399) + the tag; when the sun / sky entry carries it, the code that
-    // traces them stores L
-    if (PRIMARY && active && !(direct && env)) wf.Lacc[laneSlot] = make_float4(0.0f, 0.0f, 0.0f, u2f(tagWord));
+    if constexpr (FUSE) {
+      if (PRIMARY && cfg.mode == 1) { uint32_t hitMask = chainHeads(); if (wf.chainMask) tagWord |= hitMask << 24; }
+      directLightTraced(cx, tb, active, g, hitPos, normal, Tw, tagWord, PRIMARY, laneSlot);
+    } else {
+      bool env = directLight(cx, tb, active, g, hitPos, normal, Tw, direct ? f4(color, u2f(tagWord)) : f4(Tw, 0.0f), laneSlot);
+      // `vec3 L;` of computeLdirect (rendering.d:399) + the tag; when the sun / sky entry carries it, the kernel that
+      // traces them stores L
+      if (PRIMARY && active && !(direct && env)) wf.Lacc[laneSlot] = make_float4(0.0f, 0.0f, 0.0f, u2f(tagWord));
+      if (PRIMARY && cfg.mode == 1) chainHeads();
+    }
     if (!PRIMARY && cfg.mode == 1) bounce<false, FUSE>(cx, active, g, depth, Tp, color, hitPos, normal, laneSlot, 0u);
   }
   if constexpr (FUSE) {
-    uint32_t nInd = cx.nInd, nOccl = cx.nOccl, nEnv = cx.nEnv;
-    for (int off = 32; off > 0; off >>= 1) { nInd += __shfl_down(nInd, off); nOccl += __shfl_down(nOccl, off); nEnv += __shfl_down(nEnv, off); }
+    uint32_t nInd = cx.nInd, nOccl = cx.nOccl, nEnv = cx.nEnv, nLight = cx.nLight;
+    for (int off = 32; off > 0; off >>= 1) {
+      nInd += __shfl_down(nInd, off); nOccl += __shfl_down(nOccl, off); nEnv += __shfl_down(nEnv, off); nLight += __shfl_down(nLight, off);
+    }
     if ((threadIdx.x & 63) == 0) {
+      if (nLight) { atomicAdd(&wf.stats[STAT_RAYS_LIGHT], (unsigned long long)nLight); atomicAdd(&wf.stats[STAT_FUSED_LIGHT], (unsigned long long)nLight); }
       if (nInd) { atomicAdd(&wf.stats[STAT_RAYS_INDIRECT], (unsigned long long)nInd); atomicAdd(&wf.stats[STAT_FUSED_INDIRECT], (unsigned long long)nInd); }
       if (nOccl) { atomicAdd(&wf.stats[STAT_RAYS_OCCL], (unsigned long long)nOccl); atomicAdd(&wf.stats[STAT_FUSED_OCCL], (unsigned long long)nOccl); }
       if (nEnv) atomicAdd(&wf.stats[STAT_ENV_ENTRIES], (unsigned long long)nEnv);
@@ -1060,6 +1134,17 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg 
   __syncthreads();
   if (threadIdx.x == 0) wf.rayOut.count[T] = sCnt[0];
   if (threadIdx.x >= 1 && threadIdx.x <= (uint32_t)numKinds) wf.sh[threadIdx.x - 1].count[T] = sCnt[threadIdx.x];
+}
+
+template <bool PRIMARY, bool LDST>
+__global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, Wavefront wf,
+                                               int numKinds) {
+  shadeBody<PRIMARY, LDST, false>(sc, cfg, pm, acc, wf, numKinds);
+}
+template <bool PRIMARY>
+__global__ void __launch_bounds__(PT_FUSE_THREADS, PT_FUSE_WAVES) k_shade_traced(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc,
+                                                                  Wavefront wf, int numKinds) {
+  shadeBody<PRIMARY, true, true>(sc, cfg, pm, acc, wf, numKinds);
 }
 
 // ------------------------------------------------------------------------------------------------ accumulate
@@ -1323,13 +1408,14 @@ void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, con
   const dim3 grid(PT_SEGS), block(PT_SHADE_THREADS);
   if (wf.fuse) {
     const uint32_t all = lds + (uint32_t)sc.ldsBytes;
-    if (primary) hipLaunchKernelGGL((k_shade<true, true, true>), grid, block, all, lc.stream, sc, cfg, pm, acc, wf, numKinds);
-    else hipLaunchKernelGGL((k_shade<false, true, true>), grid, block, all, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+    const dim3 fblock(PT_FUSE_THREADS);
+    if (primary) hipLaunchKernelGGL((k_shade_traced<true>), grid, fblock, all, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+    else hipLaunchKernelGGL((k_shade_traced<false>), grid, fblock, all, lc.stream, sc, cfg, pm, acc, wf, numKinds);
   }
-  else if (primary && lds) hipLaunchKernelGGL((k_shade<true, true, false>), grid, block, lds, lc.stream, sc, cfg, pm, acc, wf, numKinds);
-  else if (primary) hipLaunchKernelGGL((k_shade<true, false, false>), grid, block, 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
-  else if (lds) hipLaunchKernelGGL((k_shade<false, true, false>), grid, block, lds, lc.stream, sc, cfg, pm, acc, wf, numKinds);
-  else hipLaunchKernelGGL((k_shade<false, false, false>), grid, block, 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+  else if (primary && lds) hipLaunchKernelGGL((k_shade<true, true>), grid, block, lds, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+  else if (primary) hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+  else if (lds) hipLaunchKernelGGL((k_shade<false, true>), grid, block, lds, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+  else hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
 }
 
 void launchAccumulate(const LaunchCfg& lc, const ViewMasks& masks, const DevCfg& cfg, const PixMap& pm, float4* acc,

@@ -406,8 +406,8 @@ def test_repeated_small_passes_replayed_from_a_graph_equal_one_render(require_gp
 @pytest.mark.parametrize('name,sky,mode', [('chest1', 1, 0), ('chest1', 1, 1), ('cornell-box', 0, 1), ('cornell-box', 1, 1),
                                            ('cornell-box', 1, 0)])
 def test_shading_that_traces_its_own_rays_equals_the_queued_path(require_gpu, name, sky, mode):
-    """Small scenes: the shading kernel traces the rays it spawns (continuation rays; sun and sky rays when no light
-    group has to be added first) instead of queueing them for extend / occluded.  Same rays, same arithmetic: the
+    """Small scenes: the shading kernel traces the rays it spawns (light-sample rays, sun and sky rays, continuation
+    rays) instead of queueing them for connect / occluded / extend.  Same rays, same arithmetic in the same order: the
     accumulators are the same bits as with PT_FLAG_NO_FUSE, every counter is equal, and the counters say which path ran."""
     W, H, spp = 96, 64, 12
     out = {}
@@ -422,14 +422,13 @@ def test_shading_that_traces_its_own_rays_equals_the_queued_path(require_gpu, na
     assert np.array_equal(a['n'], b['n']) and np.array_equal(a['sum'].view(np.uint32), b['sum'].view(np.uint32))
     for f in ('raysPrimary', 'raysLight', 'raysIndirect', 'raysOcclusion', 'raysCulled', 'hits', 'envEntries', 'samples'):
         assert getattr(sa, f) == getattr(sb, f), f
-    assert sb.raysIndirectInShade == 0 and sb.raysOcclusionInShade == 0
+    assert sb.raysIndirectInShade == 0 and sb.raysOcclusionInShade == 0 and sb.raysLightInShade == 0
     lights = name == 'cornell-box'
     assert sa.raysIndirectInShade == sa.raysIndirect and (sa.raysIndirect > 0) == (mode == 1)
-    assert sa.raysOcclusionInShade == (0 if lights else sa.raysOcclusion)
-    if sky:
-        assert sa.raysOcclusion > 0
+    assert sa.raysOcclusionInShade == sa.raysOcclusion and (sa.raysOcclusion > 0) == bool(sky)
+    assert sa.raysLightInShade == sa.raysLight and (sa.raysLight > 0) == lights
     k = list(P.PT_K_NAMES)
     assert sa.kernelLaunches[k.index('extend')] == 2      # the view rays of the two batches; indirect rays never get there
     assert sb.kernelLaunches[k.index('extend')] == (2 if mode == 0 else 2 * (2 + 4))
-    if sky and not lights:
-        assert sa.kernelLaunches[k.index('occluded')] == 0 and sb.kernelLaunches[k.index('occluded')] > 0
+    assert sa.kernelLaunches[k.index('occluded')] == 0 and sa.kernelLaunches[k.index('connect')] == 0
+    assert (sb.kernelLaunches[k.index('occluded')] > 0) == bool(sky) and (sb.kernelLaunches[k.index('connect')] > 0) == lights
