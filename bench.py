@@ -100,9 +100,10 @@ def ceilings(kind, st, visits, ms, launches, pmc, scene_in_lds):
     if not launches or ms <= 0:
         return None
     sec = ms * 1e-3
+    fused_prim = st.raysPrimaryInShade
     fused_ind, fused_occ, fused_light = st.raysIndirectInShade, st.raysOcclusionInShade, st.raysLightInShade   # rays the shading kernel traced itself
     if kind == 'extend':
-        rays = st.raysPrimary - st.raysCulled + st.raysIndirect - fused_ind
+        rays = st.raysPrimary - st.raysCulled - fused_prim + st.raysIndirect - fused_ind
         stream, nodes, tris = rays * B_STREAM_CLOSEST, rays * visits['nodes_closest'], rays * visits['tris_closest']
     elif kind == 'connect':
         rays = st.raysLight - fused_light
@@ -118,11 +119,15 @@ def ceilings(kind, st, visits, ms, launches, pmc, scene_in_lds):
         # their box and triangle tests are served from the kernel's scene copy in LDS.
         rays = st.hits
         env_queued = st.envEntries if not fused_occ else 0
-        fused = fused_ind or fused_occ or fused_light
-        stream = (st.hits * 96.0 + (st.raysLight - fused_light) * 48.0 + env_queued * 64.0 + (st.raysIndirect - fused_ind) * 32.0
-                  + (st.hitsPrimary * 16.0 + (st.hits - st.hitsPrimary) * 32.0 if fused else 0.0))
-        nodes = (fused_ind + fused_light) * visits['nodes_closest'] + fused_occ * visits['nodes_any']
-        tris = (fused_ind + fused_light) * visits['tris_closest'] + fused_occ * visits['tris_any']
+        # The whole-sample kernel (view ray generated, traced and shaded in one launch) reads the 4 B sample count of a
+        # pixel per sample and no hit record for view-ray hits.
+        fused = fused_ind or fused_occ or fused_light or fused_prim
+        hits_read = st.hits - (st.hitsPrimary if fused_prim else 0)
+        stream = (hits_read * 32.0 + st.hits * 64.0 + (st.raysLight - fused_light) * 48.0 + env_queued * 64.0
+                  + (st.raysIndirect - fused_ind) * 32.0 + (st.hitsPrimary * 16.0 + (st.hits - st.hitsPrimary) * 32.0 if fused else 0.0)
+                  + (st.samples * 4.0 + (st.samples - st.hitsPrimary - st.raysCulled) * 16.0 if fused_prim else 0.0))
+        nodes = (fused_prim + fused_ind + fused_light) * visits['nodes_closest'] + fused_occ * visits['nodes_any']
+        tris = (fused_prim + fused_ind + fused_light) * visits['tris_closest'] + fused_occ * visits['tris_any']
     else:
         return None
     scene_bytes = nodes * B_NODE + tris * B_TRI
@@ -282,7 +287,7 @@ def measure(P, torch, dist, multigpu, name, args, rank, world, local_rank, rehea
         'rays_per_sample': round(rays / max(1.0, samples), 4),
         'rays': {'primary': int(st.raysPrimary), 'primary_answered_in_raygen': int(st.raysCulled),
                  'light': int(st.raysLight), 'indirect': int(st.raysIndirect), 'occlusion': int(st.raysOcclusion),
-                 'shaded_vertices': int(st.hits), 'light_traced_in_shade': int(st.raysLightInShade), 'indirect_traced_in_shade': int(st.raysIndirectInShade),
+                 'shaded_vertices': int(st.hits), 'primary_traced_in_shade': int(st.raysPrimaryInShade), 'light_traced_in_shade': int(st.raysLightInShade), 'indirect_traced_in_shade': int(st.raysIndirectInShade),
                  'occlusion_traced_in_shade': int(st.raysOcclusionInShade)},
         'mask_build_ms': round(cst.maskBuildMs, 3),
         'device_ms_per_step_rank0': round(st.renderMs / steps, 3), 'readback_ms': round(readback_ms, 3),

@@ -76,6 +76,10 @@ typedef struct PtConfig {
                                      tables together fit in 24 KB of LDS, shading traces the rays it spawns itself --
                                      light-sample rays, sun / sky rays, continuation rays of the indirect chains --
                                      instead of queueing them; same rays, same results)                            */
+#define PT_FLAG_QUEUED_VIEW_RAYS 256u /* with traced shading: always keep raygen, extend and shade as separate launches for
+                                     the view rays (default: batches of 32 Mi samples or more generate a sample's view
+                                     ray, trace it and shade its hit in one kernel)                                  */
+#define PT_FLAG_WHOLE_SAMPLE_KERNEL 512u /* with traced shading: that one kernel whatever the batch size             */
 
 typedef struct PtMaterial { float emissive; float color[3]; } PtMaterial;        /* rendering.d:33-37 */
 typedef struct PtPixel { float color[3]; float n; float sum[3]; } PtPixel;        /* rendering.d:24-30 */
@@ -96,7 +100,8 @@ typedef struct PtStats {
   uint64_t hits;             /* Scene.trace calls of computeL / computeLindirect that hit: vertices shaded     */
   uint64_t envEntries;       /* shaded vertices that trace a sun ray, a sky ray or both (one queue entry each) */
   uint64_t hitsPrimary;      /* of hits: view rays that hit                                                    */
-  uint64_t raysLightInShade;     /* of raysLight / raysIndirect / raysOcclusion: rays the shading kernel traced itself */
+  uint64_t raysPrimaryInShade;   /* of raysPrimary / raysLight / raysIndirect / raysOcclusion: rays the shading kernel */
+  uint64_t raysLightInShade;     /* (or the whole-sample kernel) traced itself                                          */
   uint64_t raysIndirectInShade;  /* instead of queueing them for the traversal kernels (small scenes, see              */
   uint64_t raysOcclusionInShade; /* PT_FLAG_NO_FUSE)                                                                   */
   double kernelMs[PT_K_COUNT];          /* with PT_FLAG_TIME_KERNELS: summed event time per kernel kind   */

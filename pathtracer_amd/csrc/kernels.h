@@ -162,9 +162,11 @@ struct Wavefront {
 
 // Scene and tables of the fused shading variant share a shade workgroup's LDS; above this the general path runs.
 constexpr uint32_t PT_FUSE_LDS_BYTES = 24 * 1024;
+// Batches from this many samples up run raygen, view-ray trace and the shading of view-ray hits as one kernel.
+constexpr uint32_t PT_WHOLE_SAMPLE_MIN_SLOTS = 1u << 25;
 
 enum { STAT_RAYS_LIGHT = 0, STAT_RAYS_INDIRECT, STAT_RAYS_OCCL, STAT_NODES_CLOSEST, STAT_TRIS_CLOSEST,
-       STAT_NODES_ANY, STAT_TRIS_ANY, STAT_RAYS_CULLED, STAT_HITS, STAT_ENV_ENTRIES, STAT_FUSED_INDIRECT, STAT_FUSED_OCCL, STAT_HITS_PRIMARY, STAT_FUSED_LIGHT,
+       STAT_NODES_ANY, STAT_TRIS_ANY, STAT_RAYS_CULLED, STAT_HITS, STAT_ENV_ENTRIES, STAT_FUSED_INDIRECT, STAT_FUSED_OCCL, STAT_HITS_PRIMARY, STAT_FUSED_LIGHT, STAT_FUSED_PRIMARY,
        STAT_COUNT };
 
 // Workgroups of a traversal kernel per CU when the scene copy in LDS takes `bytes` (0: it does not fit at all).
@@ -209,6 +211,10 @@ __device__ __forceinline__ float4 loadLacc(const float4* Lacc, uint32_t slot, ui
 }
 // primary: the queue was filled by the shading of view-ray hits
 void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, bool primary);
+// raygen + trace of the view rays + shading of their hits in one launch (wf.fuse != 0): fills the radiance records and
+// wf.rayOut = the hit queue of the chains' first rays
+void launchSampleTraced(const LaunchCfg& lc, const SceneBox& box, const ViewMasks& masks, const DevScene& sc, const DevCfg& cfg,
+                        const PixMap& pm, const float4* acc, uint32_t nslots, const Wavefront& wf);
 void launchAccumulate(const LaunchCfg& lc, const ViewMasks& masks, const DevCfg& cfg, const PixMap& pm, float4* acc,
                       const Wavefront& wf, const DevScene& sc);
 

@@ -1028,6 +1028,74 @@ __device__ __forceinline__ void directLightTraced(ShadeCtx& cx, const ShadeTable
 // dozen triangles that traffic is what the launches wait for.  PRIMARY: a chain whose first ray hit
 // something is noted in the top bits of the view-ray record's tag word (wf.chainMask), so that accumulate reads only
 // the chain records that can hold anything.
+// What shading reads of the triangle that was hit: the interpolated normal (scene.d:711-723), the material's colour
+// and the tag (material index + 1) that marks a view-ray record as a hit.
+template <bool LDST>
+__device__ __forceinline__ void vertexTables(const ShadeTables<LDST>& tb, uint32_t tri, float u, float v, V3& normal, V3& color, uint32_t& matTag) {
+  float4 q0 = tb.nrm(3 * tri), q1 = tb.nrm(3 * tri + 1), q2 = tb.nrm(3 * tri + 2);
+  normal = interpNormal(xyz(q0), xyz(q1), xyz(q2), u, v);
+  float4 m = tb.mat(f2u(q0.w));
+  color = v3(m.y, m.z, m.w);
+  matTag = f2u(q0.w) + 1u;
+}
+
+// One vertex: computeLdirect, and the heads of the indirect chains (PRIMARY, rendering.d:474-476) or the chain's
+// continuation (rendering.d:376-394).  Called from converged code (the appends rank lanes with a wave ballot);
+// `active` says whether the lane has a vertex.  g: the vertex's generator (view-ray hit: stream 0 of its sample past
+// the two jitter draws; chain hit: the chain's stream).
+template <bool PRIMARY, bool LDST, bool FUSE>
+__device__ __forceinline__ void shadeVertex(ShadeCtx& cx, const ShadeTables<LDST>& tb, bool active, V3 hitPos, V3 normal, V3 color,
+                                            uint32_t matTag, V3 Tp, uint32_t depth, Rng& g, uint32_t gp, uint32_t sampleIdx,
+                                            uint32_t laneSlot) {
+  const DevCfg& cfg = cx.cfg; const Wavefront& wf = cx.wf;
+  uint32_t tagWord = matTag;
+  // every chain has a generator stream of its own, so the place of the loop in this kernel is free: the traced
+  // variant runs it ahead of computeLdirect, because the record that carries the tag word (with the chains that hit)
+  // is written there
+  auto chainHeads = [&]() {
+    uint32_t hitMask = 0;
+#ifdef PT_PROBE_B
+    for (uint32_t c = 0; c < 0; c++) {
+#else
+    for (uint32_t c = 0; c < cfg.numIndirect; c++) {
+#endif
+      uint32_t lane = (c + 1) * wf.capSlots + laneSlot;
+      Rng gc; gc.s0 = 1; gc.s1 = 0;
+      if (active) gc.seed(cfg.seed, gp, sampleIdx, c + 1);
+      if (bounce<true, FUSE>(cx, active, gc, 0, v3(1, 1, 1), color, hitPos, normal, lane, matTag - 1u)) hitMask |= 1u << c;
+    }
+    return hitMask;
+  };
+  V3 Tw = Tp * (PT_BRDF * color);
+  if constexpr (FUSE) {
+    if (PRIMARY && cfg.mode == 1) { uint32_t hitMask = chainHeads(); if (wf.chainMask) tagWord |= hitMask << 24; }
+    directLightTraced(cx, tb, active, g, hitPos, normal, Tw, tagWord, PRIMARY, laneSlot);
+  } else {
+    const bool direct = envDirect(cfg, cx.sc, PRIMARY);
+    bool env = directLight(cx, tb, active, g, hitPos, normal, Tw, direct ? f4(color, u2f(tagWord)) : f4(Tw, 0.0f), laneSlot);
+    // `vec3 L;` of computeLdirect (rendering.d:399) + the tag; when the sun / sky entry carries it, the kernel that
+    // traces them stores L
+    if (PRIMARY && active && !(direct && env)) wf.Lacc[laneSlot] = make_float4(0.0f, 0.0f, 0.0f, u2f(tagWord));
+    if (PRIMARY && cfg.mode == 1) chainHeads();
+  }
+  if (!PRIMARY && cfg.mode == 1) bounce<false, FUSE>(cx, active, g, depth, Tp, color, hitPos, normal, laneSlot, 0u);
+}
+
+// Ray counts of the traced variants: wave sums, one atomic per wave and counter.
+__device__ __forceinline__ void flushTraced(ShadeCtx& cx) {
+  uint32_t nInd = cx.nInd, nOccl = cx.nOccl, nEnv = cx.nEnv, nLight = cx.nLight;
+  for (int off = 32; off > 0; off >>= 1) {
+    nInd += __shfl_down(nInd, off); nOccl += __shfl_down(nOccl, off); nEnv += __shfl_down(nEnv, off); nLight += __shfl_down(nLight, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long* st = cx.wf.stats;
+    if (nLight) { atomicAdd(&st[STAT_RAYS_LIGHT], (unsigned long long)nLight); atomicAdd(&st[STAT_FUSED_LIGHT], (unsigned long long)nLight); }
+    if (nInd) { atomicAdd(&st[STAT_RAYS_INDIRECT], (unsigned long long)nInd); atomicAdd(&st[STAT_FUSED_INDIRECT], (unsigned long long)nInd); }
+    if (nOccl) { atomicAdd(&st[STAT_RAYS_OCCL], (unsigned long long)nOccl); atomicAdd(&st[STAT_FUSED_OCCL], (unsigned long long)nOccl); }
+    if (nEnv) atomicAdd(&st[STAT_ENV_ENTRIES], (unsigned long long)nEnv);
+  }
+}
+
 template <bool PRIMARY, bool LDST, bool FUSE>
 __device__ __forceinline__ void shadeBody(const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* __restrict__ acc,
                                           const Wavefront& wf, int numKinds) {
@@ -1042,7 +1110,6 @@ __device__ __forceinline__ void shadeBody(const DevScene& sc, const DevCfg& cfg,
   uint32_t segCap = wf.capQueue / PT_SEGS;
   ShadeCtx cx{sc, cfg, wf, sCnt, T, segCap, segCap};
   cx.segCapHit = wf.capHit / PT_SEGS;
-  const bool direct = envDirect(cfg, sc, PRIMARY);
   Task tk = taskOf(wf.hitQ, T);
   SegCursor seg = segCursor(wf.hitQ, tk.seg);
   const FastDiv divCap = wf.divCap;
@@ -1082,55 +1149,11 @@ __device__ __forceinline__ void shadeBody(const DevScene& sc, const DevCfg& cfg,
         float4 t4 = wf.thr[laneSlot]; Tp = xyz(t4); depth = f2u(t4.w);
         uint2 r = wf.rng[laneSlot]; g.s0 = r.x; g.s1 = r.y;
       }
-      float4 q0 = tb.nrm(3 * tri), q1 = tb.nrm(3 * tri + 1), q2 = tb.nrm(3 * tri + 2);
-      normal = interpNormal(xyz(q0), xyz(q1), xyz(q2), hb.x, hb.y);
-      float4 m = tb.mat(f2u(q0.w));
-      color = v3(m.y, m.z, m.w);
-      matTag = f2u(q0.w) + 1u;
+      vertexTables(tb, tri, hb.x, hb.y, normal, color, matTag);
     }
-    uint32_t tagWord = matTag;
-    // the loop at rendering.d:474-476; every chain has a generator stream of its own, so its place in this kernel is
-    // free: the traced variant runs it ahead of computeLdirect, because the record that carries the tag word (with
-    // the chains that hit) is written there
-    auto chainHeads = [&]() {
-      uint32_t hitMask = 0;
-#ifdef PT_PROBE_B
-      for (uint32_t c = 0; c < 0; c++) {
-#else
-      for (uint32_t c = 0; c < cfg.numIndirect; c++) {
-#endif
-        uint32_t lane = (c + 1) * wf.capSlots + laneSlot;
-        Rng gc; gc.s0 = 1; gc.s1 = 0;
-        if (active) gc.seed(cfg.seed, gp, sampleIdx, c + 1);
-        if (bounce<true, FUSE>(cx, active, gc, 0, v3(1, 1, 1), color, hitPos, normal, lane, matTag - 1u)) hitMask |= 1u << c;
-      }
-      return hitMask;
-    };
-    V3 Tw = Tp * (PT_BRDF * color);
-    if constexpr (FUSE) {
-      if (PRIMARY && cfg.mode == 1) { uint32_t hitMask = chainHeads(); if (wf.chainMask) tagWord |= hitMask << 24; }
-      directLightTraced(cx, tb, active, g, hitPos, normal, Tw, tagWord, PRIMARY, laneSlot);
-    } else {
-      bool env = directLight(cx, tb, active, g, hitPos, normal, Tw, direct ? f4(color, u2f(tagWord)) : f4(Tw, 0.0f), laneSlot);
-      // `vec3 L;` of computeLdirect (rendering.d:399) + the tag; when the sun / sky entry carries it, the kernel that
-      // traces them stores L
-      if (PRIMARY && active && !(direct && env)) wf.Lacc[laneSlot] = make_float4(0.0f, 0.0f, 0.0f, u2f(tagWord));
-      if (PRIMARY && cfg.mode == 1) chainHeads();
-    }
-    if (!PRIMARY && cfg.mode == 1) bounce<false, FUSE>(cx, active, g, depth, Tp, color, hitPos, normal, laneSlot, 0u);
+    shadeVertex<PRIMARY, LDST, FUSE>(cx, tb, active, hitPos, normal, color, matTag, Tp, depth, g, gp, sampleIdx, laneSlot);
   }
-  if constexpr (FUSE) {
-    uint32_t nInd = cx.nInd, nOccl = cx.nOccl, nEnv = cx.nEnv, nLight = cx.nLight;
-    for (int off = 32; off > 0; off >>= 1) {
-      nInd += __shfl_down(nInd, off); nOccl += __shfl_down(nOccl, off); nEnv += __shfl_down(nEnv, off); nLight += __shfl_down(nLight, off);
-    }
-    if ((threadIdx.x & 63) == 0) {
-      if (nLight) { atomicAdd(&wf.stats[STAT_RAYS_LIGHT], (unsigned long long)nLight); atomicAdd(&wf.stats[STAT_FUSED_LIGHT], (unsigned long long)nLight); }
-      if (nInd) { atomicAdd(&wf.stats[STAT_RAYS_INDIRECT], (unsigned long long)nInd); atomicAdd(&wf.stats[STAT_FUSED_INDIRECT], (unsigned long long)nInd); }
-      if (nOccl) { atomicAdd(&wf.stats[STAT_RAYS_OCCL], (unsigned long long)nOccl); atomicAdd(&wf.stats[STAT_FUSED_OCCL], (unsigned long long)nOccl); }
-      if (nEnv) atomicAdd(&wf.stats[STAT_ENV_ENTRIES], (unsigned long long)nEnv);
-    }
-  }
+  if constexpr (FUSE) flushTraced(cx);
   __syncthreads();
   if (threadIdx.x == 0) wf.rayOut.count[T] = sCnt[0];
   if (threadIdx.x >= 1 && threadIdx.x <= (uint32_t)numKinds) wf.sh[threadIdx.x - 1].count[T] = sCnt[threadIdx.x];
@@ -1145,6 +1168,74 @@ template <bool PRIMARY>
 __global__ void __launch_bounds__(PT_FUSE_THREADS, PT_FUSE_WAVES) k_shade_traced(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc,
                                                                   Wavefront wf, int numKinds) {
   shadeBody<PRIMARY, true, true>(sc, cfg, pm, acc, wf, numKinds);
+}
+
+// A whole sample in one kernel, for the scenes the traced shading handles: raygen (getViewRay, the view-ray masks),
+// Scene.trace of the view ray and the shading of its hit, slot by slot -- no view-ray queue, no hit queue for view
+// rays, no generator re-seeded in shade (the lane still holds the sample's stream past its two jitter draws).  What
+// leaves the kernel is the sample's radiance record and the hits of the chains' first rays.
+__global__ void __launch_bounds__(PT_FUSE_THREADS, PT_FUSE_WAVES) k_sample_traced(SceneBox box, ViewMasks masks, DevScene sc, DevCfg cfg, PixMap pm,
+                                                                   const float4* __restrict__ acc, uint32_t nslots, Wavefront wf) {
+  __shared__ uint32_t sCnt[1 + PT_MAX_KINDS];
+  if (threadIdx.x <= PT_MAX_KINDS) sCnt[threadIdx.x] = 0;
+  stageScene<true>(sc);
+  const ShadeTables<true> tb{sc, 2 * sc.numNodes + 3 * sc.numTris};
+  tb.stage();
+  __syncthreads();
+  // Runs of 64 slots (one wave: a tile of pixels at one sample number) are dealt out to the block-tasks in turn, run c
+  // to task c % PT_SEGS, and a task's runs to its waves in turn: the work of a run ranges from nothing (sky) to a
+  // vertex with all its rays, and contiguous shares would leave the tasks that cover background idle.  A task gets at
+  // most capSlots / (64 * PT_SEGS) runs, so what it appends fits its segment.  Waves do not wait for each other.
+  const uint32_t T = blockIdx.x, runs = (nslots + 63u) >> 6;
+  const uint32_t segCap = wf.capQueue / PT_SEGS;
+  ShadeCtx cx{sc, cfg, wf, sCnt, T, segCap, segCap};
+  cx.segCapHit = wf.capHit / PT_SEGS;
+  uint32_t culled = 0, hits = 0, mine = 0;
+  for (uint32_t run = T + PT_SEGS * (threadIdx.x >> 6); run < runs; run += PT_SEGS * (blockDim.x >> 6)) {
+    const uint32_t i = (run << 6) + (threadIdx.x & 63u);
+    const bool valid = i < nslots;
+    if (valid) mine++;
+    uint32_t s, gp = slotPixel(cfg, pm, valid ? i : 0u, s);
+    const bool constant = valid && masks.constantSky && maskBit(masks.constantSky, gp);
+    const bool live = valid && !constant;
+    bool active = false;
+    V3 hitPos = v3(0, 0, 0), normal = v3(0, 0, 1), color = v3(0, 0, 0);
+    uint32_t matTag = 0, sampleIdx = 0;
+    Rng g; g.s0 = 1; g.s1 = 0;
+    if (constant) culled++;
+    if (live) {
+      PrimaryRay pr = primaryRayFrom(cfg, gp, s, acc[gp].w, true);
+      bool enter;
+      if (masks.covered) enter = maskBit(masks.covered, gp);
+      else {
+        RayInv ri = makeRayInv(cfg.cam.pos, pr.d);
+        float tn;
+        enter = slab(ri, box.mn[0], box.mn[1], box.mn[2], box.mx[0], box.mx[1], box.mx[2], PT_FLT_MAX, tn);
+      }
+      Hit h; h.t = 0; h.u = 0; h.v = 0; h.tri = 0;
+      if (enter) { uint32_t cN = 0, cT = 0; active = traverse<false, true, false, PT_FUSE_OCTANTS>(sc, cfg.cam.pos, pr.d, cfg.eps, h, cN, cT); }
+      else culled++;
+      if (active) {
+        hitPos = cfg.cam.pos + pr.d * h.t;
+        vertexTables(tb, h.tri, h.u, h.v, normal, color, matTag);
+        g = pr.g; sampleIdx = pr.sampleIdx; hits++;
+      } else {
+        wf.Lacc[i] = f4(sampleSky(pr.d), 0.0f);                                     // rendering.d:480
+      }
+    }
+    shadeVertex<true, true, true>(cx, tb, active, hitPos, normal, color, matTag, v3(1, 1, 1), 0u, g, gp, sampleIdx, i);
+  }
+  flushTraced(cx);
+  for (int off = 32; off > 0; off >>= 1) { culled += __shfl_down(culled, off); hits += __shfl_down(hits, off); mine += __shfl_down(mine, off); }
+  if ((threadIdx.x & 63) == 0) {
+    if (culled) atomicAdd(&wf.stats[STAT_RAYS_CULLED], (unsigned long long)culled);
+    if (hits) {
+      atomicAdd(&wf.stats[STAT_HITS], (unsigned long long)hits); atomicAdd(&wf.stats[STAT_HITS_PRIMARY], (unsigned long long)hits);
+    }
+    if (mine > culled) atomicAdd(&wf.stats[STAT_FUSED_PRIMARY], (unsigned long long)(mine - culled));     // view rays traced here
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) wf.rayOut.count[T] = sCnt[0];
 }
 
 // ------------------------------------------------------------------------------------------------ accumulate
@@ -1416,6 +1507,12 @@ void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, con
   else if (primary) hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
   else if (lds) hipLaunchKernelGGL((k_shade<false, true>), grid, block, lds, lc.stream, sc, cfg, pm, acc, wf, numKinds);
   else hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+}
+
+void launchSampleTraced(const LaunchCfg& lc, const SceneBox& box, const ViewMasks& masks, const DevScene& sc, const DevCfg& cfg,
+                        const PixMap& pm, const float4* acc, uint32_t nslots, const Wavefront& wf) {
+  const uint32_t all = shadeTableBytes(sc) + (uint32_t)sc.ldsBytes;
+  hipLaunchKernelGGL(k_sample_traced, dim3(PT_SEGS), dim3(PT_FUSE_THREADS), all, lc.stream, box, masks, sc, cfg, pm, acc, nslots, wf);
 }
 
 void launchAccumulate(const LaunchCfg& lc, const ViewMasks& masks, const DevCfg& cfg, const PixMap& pm, float4* acc,

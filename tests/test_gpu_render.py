@@ -411,24 +411,28 @@ def test_shading_that_traces_its_own_rays_equals_the_queued_path(require_gpu, na
     accumulators are the same bits as with PT_FLAG_NO_FUSE, every counter is equal, and the counters say which path ran."""
     W, H, spp = 96, 64, 12
     out = {}
-    for flags in (0, P.PT_FLAG_NO_FUSE):
+    for flags in (P.PT_FLAG_WHOLE_SAMPLE_KERNEL, P.PT_FLAG_NO_FUSE, P.PT_FLAG_QUEUED_VIEW_RAYS, 0):
         pt = make_tracer(name, W, H, has_sky=sky, mode=mode, seed=77, max_depth=4, flags=flags | P.PT_FLAG_TIME_KERNELS)
         pt.render_frame(spp)
         pt.render_frame(3)                                # a second batch: chain records of the first carry an older tag
         st = pt.stats()
         out[flags] = (pt.read_pixels(), st)
         pt.close()
-    (a, sa), (b, sb) = out[0], out[P.PT_FLAG_NO_FUSE]
-    assert np.array_equal(a['n'], b['n']) and np.array_equal(a['sum'].view(np.uint32), b['sum'].view(np.uint32))
-    for f in ('raysPrimary', 'raysLight', 'raysIndirect', 'raysOcclusion', 'raysCulled', 'hits', 'envEntries', 'samples'):
-        assert getattr(sa, f) == getattr(sb, f), f
+    (a, sa), (b, sb), (c, sc) = out[P.PT_FLAG_WHOLE_SAMPLE_KERNEL], out[P.PT_FLAG_NO_FUSE], out[P.PT_FLAG_QUEUED_VIEW_RAYS]
+    assert out[0][1].raysPrimaryInShade == 0          # a batch this small takes the separate launches by default
+    for x, sx in ((b, sb), (c, sc)):
+        assert np.array_equal(a['n'], x['n']) and np.array_equal(a['sum'].view(np.uint32), x['sum'].view(np.uint32))
+        for f in ('raysPrimary', 'raysLight', 'raysIndirect', 'raysOcclusion', 'raysCulled', 'hits', 'hitsPrimary', 'envEntries', 'samples'):
+            assert getattr(sa, f) == getattr(sx, f), f
+    assert sa.raysPrimaryInShade == sa.raysPrimary - sa.raysCulled > 0 and sb.raysPrimaryInShade == 0 and sc.raysPrimaryInShade == 0
+    assert sc.raysIndirectInShade == sa.raysIndirectInShade and sc.raysOcclusionInShade == sa.raysOcclusionInShade
     assert sb.raysIndirectInShade == 0 and sb.raysOcclusionInShade == 0 and sb.raysLightInShade == 0
     lights = name == 'cornell-box'
     assert sa.raysIndirectInShade == sa.raysIndirect and (sa.raysIndirect > 0) == (mode == 1)
     assert sa.raysOcclusionInShade == sa.raysOcclusion and (sa.raysOcclusion > 0) == bool(sky)
     assert sa.raysLightInShade == sa.raysLight and (sa.raysLight > 0) == lights
     k = list(P.PT_K_NAMES)
-    assert sa.kernelLaunches[k.index('extend')] == 2      # the view rays of the two batches; indirect rays never get there
+    assert sa.kernelLaunches[k.index('extend')] == 0 and sc.kernelLaunches[k.index('extend')] == 2      # view rays of two batches
     assert sb.kernelLaunches[k.index('extend')] == (2 if mode == 0 else 2 * (2 + 4))
     assert sa.kernelLaunches[k.index('occluded')] == 0 and sa.kernelLaunches[k.index('connect')] == 0
     assert (sb.kernelLaunches[k.index('occluded')] > 0) == bool(sky) and (sb.kernelLaunches[k.index('connect')] > 0) == lights
