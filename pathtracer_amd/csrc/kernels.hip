@@ -461,7 +461,8 @@ __device__ __forceinline__ void initPool(WorkPool* p) {
 // Next chunk for the calling wave (wave-uniform result); false when the queue is drained.  outLimit != 0: the
 // workgroup appends at most one entry per input entry to a region of outLimit entries counted in p->out, and stops
 // taking input when the entries already taken plus a new refill could overflow the region.
-__device__ __forceinline__ bool nextChunk(WorkPool* p, uint32_t* counter, const QMeta& q, uint32_t total, uint32_t outLimit, Chunk& c) {
+__device__ __forceinline__ bool nextChunk(WorkPool* p, uint32_t* counter, const QMeta& q, uint32_t total, uint32_t outLimit, Chunk& c,
+                                          uint32_t inFlight = 0) {
   uint32_t b = 0xFFFFFFFFu, e = 0, s = 0;
   if ((threadIdx.x & 63) == 0) {
     volatile WorkPool* vp = p;
@@ -476,7 +477,8 @@ __device__ __forceinline__ bool nextChunk(WorkPool* p, uint32_t* counter, const 
       if (atomicCAS(&p->lock, 0u, 1u) == 0u) {
         st = vp->state;
         if ((uint32_t)st >= (uint32_t)(st >> 32) && !vp->done) {
-          bool full = outLimit && vp->out + blockDim.x + PT_SUPER > outLimit;   // + blockDim.x: chunks in flight
+          // + entries taken from the pool but not yet decided: a chunk per wave, or what the caller says
+          bool full = outLimit && vp->out + (inFlight ? inFlight : blockDim.x) + PT_SUPER > outLimit;
           // a short queue is handed out in smaller pieces, so that every workgroup of the launch gets some of it: with
           // PT_SUPER entries a piece, 76 800 rays (a 320 x 240 pass) would keep 38 workgroups busy and leave the rest idle
           const uint32_t piece = min(PT_SUPER, max(blockDim.x, ((total + gridDim.x - 1) / gridDim.x + 63u) & ~63u));
@@ -628,7 +630,11 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend(DevScene sc, DevCfg cfg, PixMap pm,
     bool isHit = false;
     V3 hitPos = v3(0, 0, 0); Hit h; h.t = 0; h.u = 0; h.v = 0; h.tri = 0; uint32_t slot = 0;
     float carry = 0.0f;                       // fourth word of an indirect ray's direction record, handed on to shade
+#ifdef PT_PROBE_HALF
+    if (j < ck.end && (threadIdx.x & 63u) < PT_PROBE_HALF) {
+#else
     if (j < ck.end) {
+#endif
       uint32_t e = physIndexHint(q, j, ck.seg, segCapIn, cur);
       V3 o, d;
       if (PRIMARY) {
@@ -650,6 +656,106 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend(DevScene sc, DevCfg cfg, PixMap pm,
     }
   }
   flushCounts<COUNT>(wf.stats, STAT_NODES_CLOSEST, cN, cT);
+  __syncthreads();
+  uint32_t n = pool.out;
+  for (uint32_t s = segFirst + threadIdx.x; s < segLast; s += blockDim.x) {
+    uint32_t before = (s - segFirst) * segCapOut;
+    wf.hitQ.count[s] = n > before ? min(n - before, segCapOut) : 0u;
+  }
+}
+
+// Extend for scenes traversed from global memory, with lanes that take a new ray when theirs is decided.  There a step
+// is a memory round trip, rays of one wave differ several-fold in the number of steps they take, and a wave that runs
+// its 64 rays to the end spends most of its load instructions on a few lanes (18 % of the lanes active per vector
+// instruction on the 10 M-triangle soup).  Here a wave keeps its traversal state per lane across rays: whenever fewer
+// than PT_REFILL_BELOW lanes are still traversing it writes out the decided rays and hands the free lanes the next
+// entries of its chunk (a new chunk from the pool when that is used up), until the queue is drained.  The traversal is
+// the postponed-leaf loop of traverseOct, resumable.  A ray's result does not depend on its lane or its companions.
+#ifndef PT_REFILL_BELOW
+#define PT_REFILL_BELOW 40
+#endif
+template <bool PRIMARY>
+__global__ void PT_TRAVERSAL_BOUNDS k_extend_refill(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, Wavefront wf) {
+  __shared__ __align__(16) WorkPool pool;
+  initPool(&pool);
+  __syncthreads();
+  const QMeta q = wf.rayIn;
+  const uint32_t total = q.prefix[PT_SEGS];
+  const uint32_t segCapIn = (PRIMARY ? wf.capSlots : wf.capQueue) / PT_SEGS, segCapOut = wf.capHit / PT_SEGS;
+  const uint32_t segFirst = (uint32_t)(((uint64_t)blockIdx.x * PT_SEGS) / gridDim.x);
+  const uint32_t segLast = (uint32_t)(((uint64_t)(blockIdx.x + 1) * PT_SEGS) / gridDim.x);
+  const uint32_t outBase = segFirst * segCapOut, outLimit = (segLast - segFirst) * segCapOut;
+  if (!PRIMARY && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&wf.stats[STAT_RAYS_INDIRECT], (unsigned long long)total);
+  SegCursor cur; cur.seg = 0; cur.lo = 1; cur.hi = 0;
+  // the lane's ray and where its traversal stands
+  bool hasRay = false, found = false;
+  V3 o = v3(0, 0, 0), d = v3(0, 0, 0); uint32_t slot = 0; float carry = 0.0f;
+  RayInv ri = makeRayInv(v3(0, 0, 0), v3(1, 1, 1));
+  Hit h; h.t = PT_FLT_MAX; h.u = 0; h.v = 0; h.tri = 0xFFFFFFFFu; h.front = true;
+  uint32_t ref = PT_NONE, leaf = PT_NONE, stack[64]; int sp = 0;
+  // the wave's share of the queue that is not handed to a lane yet
+  uint32_t cb = 0, ce = 0, cseg = 0; bool supply = true;
+  for (;;) {
+    bool need = !hasRay;
+    while (supply && __any(need)) {
+      if (cb == ce) {
+        Chunk ck;
+        // decided-but-unwritten and unstarted entries of this workgroup: at most a wave of rays and a chunk per wave
+        if (!nextChunk(&pool, wf.taskCounters, q, total, outLimit, ck, 2u * blockDim.x)) { supply = false; break; }
+        cb = ck.begin; ce = ck.end; cseg = ck.seg;
+      }
+      const unsigned long long m = __ballot(need);
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      const uint32_t n = min((uint32_t)__popcll(m), ce - cb);
+      if (need && rank < n) {
+        uint32_t e = physIndexHint(q, cb + rank, cseg, segCapIn, cur);
+        if (PRIMARY) {
+          float4 sd = wf.slotQ[e];
+          o = cfg.cam.pos; d = xyz(sd); slot = f2u(sd.w);
+        } else {
+          float4 ro = wf.rayO[e], rd = wf.rayD[e];
+          o = xyz(ro); d = xyz(rd); slot = f2u(ro.w); carry = rd.w;
+        }
+        ri = makeRayInv(o, d, v3(sc.qBase[0], sc.qBase[1], sc.qBase[2]));
+        ri.a0x = fmaf(sc.qBase[0], ri.ix, ri.a0x); ri.a1x = fmaf(sc.qBase[0], ri.ix, ri.a1x); ri.ix = sc.qScale[0] * ri.ix;
+        ri.a0y = fmaf(sc.qBase[1], ri.iy, ri.a0y); ri.a1y = fmaf(sc.qBase[1], ri.iy, ri.a1y); ri.iy = sc.qScale[1] * ri.iy;
+        ri.a0z = fmaf(sc.qBase[2], ri.iz, ri.a0z); ri.a1z = fmaf(sc.qBase[2], ri.iz, ri.a1z); ri.iz = sc.qScale[2] * ri.iz;
+        h.t = PT_FLT_MAX; h.u = 0.0f; h.v = 0.0f; h.tri = 0xFFFFFFFFu; found = false;
+        sp = 0; ref = sc.rootRef; leaf = PT_NONE;
+        if (isLeaf(ref)) { leaf = ref; ref = PT_NONE; }
+        hasRay = true; need = false;
+      }
+      cb += n;
+    }
+    if (!__any(hasRay)) break;
+    const uint32_t minBusy = supply ? (uint32_t)PT_REFILL_BELOW : 1u;
+    for (;;) {
+      const bool busy = ref != PT_NONE || leaf != PT_NONE;
+      if ((uint32_t)__popcll(__ballot(busy)) < minBusy) break;
+      while (isInternal(ref)) {
+        ref = stepDown<false, -1, false>(sc, ri, h.t, ref, stack, sp);
+        if (leaf == PT_NONE && isLeaf(ref)) { leaf = ref; ref = sp ? popRef(stack, sp) : PT_NONE; }
+        if (!__any(leaf == PT_NONE && ref != PT_NONE)) break;
+      }
+      while (leaf != PT_NONE) {
+        uint32_t cnt = leaf >> BVH_COUNT_SHIFT, first = leaf & BVH_INDEX_MASK;
+        for (uint32_t i = 0; i < cnt; i++) testTriangle<false, false>(sc, (first + i) * 3, o, d, cfg.eps, h, found);
+        leaf = PT_NONE;
+        if (isLeaf(ref)) { leaf = ref; ref = sp ? popRef(stack, sp) : PT_NONE; }
+      }
+    }
+    const bool fin = hasRay && ref == PT_NONE && leaf == PT_NONE;
+    const bool isHit = fin && found;
+    uint32_t idx = waveAppend(isHit, &pool.out);
+    if (isHit) {
+      uint32_t e = outBase + idx;
+      wf.hitA[e] = f4(o + d * h.t, u2f(h.tri));
+      wf.hitB[e] = make_float4(h.u, h.v, u2f(slot), PRIMARY ? h.t : carry);
+    } else if (fin && PRIMARY) {
+      wf.Lacc[slot] = f4(sampleSky(d), 0.0f);
+    }
+    if (fin) hasRay = false;
+  }
   __syncthreads();
   uint32_t n = pool.out;
   for (uint32_t s = segFirst + threadIdx.x; s < segLast; s += blockDim.x) {
@@ -1469,6 +1575,7 @@ static void dispatchExtend(const LaunchCfg& lc, const DevScene& sc, const DevCfg
   if (l_ && c_) { allowLds(lc, (const void*)k_extend<PRIMARY, true, true>, g.lds); hipLaunchKernelGGL((k_extend<PRIMARY, true, true>), g.grid, g.block, g.lds, lc.stream, sc, cfg, pm, acc, wf); }
   else if (l_) { allowLds(lc, (const void*)k_extend<PRIMARY, true, false>, g.lds); hipLaunchKernelGGL((k_extend<PRIMARY, true, false>), g.grid, g.block, g.lds, lc.stream, sc, cfg, pm, acc, wf); }
   else if (c_) hipLaunchKernelGGL((k_extend<PRIMARY, false, true>), g.grid, g.block, 0, lc.stream, sc, cfg, pm, acc, wf);
+  else if (PT_REFILL_BELOW) hipLaunchKernelGGL((k_extend_refill<PRIMARY>), g.grid, g.block, 0, lc.stream, sc, cfg, pm, acc, wf);
   else hipLaunchKernelGGL((k_extend<PRIMARY, false, false>), g.grid, g.block, 0, lc.stream, sc, cfg, pm, acc, wf);
 }
 
