@@ -80,6 +80,9 @@ typedef struct PtConfig {
                                      the view rays (default: batches of 32 Mi samples or more generate a sample's view
                                      ray, trace it and shade its hit in one kernel)                                  */
 #define PT_FLAG_WHOLE_SAMPLE_KERNEL 512u /* with traced shading: that one kernel whatever the batch size             */
+#define PT_FLAG_NO_TREELETS 1024u   /* scenes traversed from global memory: keep the builder's order of the node pairs
+                                     (default: pairs are laid out so that a 128-byte line holds a pair with
+                                     descendants of it)                                                              */
 
 typedef struct PtMaterial { float emissive; float color[3]; } PtMaterial;        /* rendering.d:33-37 */
 typedef struct PtPixel { float color[3]; float n; float sum[3]; } PtPixel;        /* rendering.d:24-30 */

@@ -259,6 +259,15 @@ void uploadScene(PtHandle* h) {
     }
   }
   h->st.bvhOnGpu = onGpu ? 1u : 0u; h->st.bvhBuildSeconds = h->bvh.buildSeconds;
+  {
+    // a scene that will be traversed from global memory gets its node pairs laid out by cache line
+    const size_t lds = ((size_t)2 * h->bvh.numNodes + (size_t)3 * h->bvh.triOrder.size()) * 16;
+    if (((f & PT_FLAG_NO_LDS_SCENE) || lds > 156 * 1024) && !(f & PT_FLAG_NO_TREELETS)) {
+      const auto t0 = std::chrono::steady_clock::now();
+      treeletLayout(h->bvh);
+      h->st.bvhBuildSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+  }
   const Bvh& bvh = h->bvh;
 
   // triangles in leaf order: (v0, origId) (v2 - v0) (v1 - v0)

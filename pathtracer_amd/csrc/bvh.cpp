@@ -156,6 +156,61 @@ void buildBvh(const float* v, uint32_t T, uint32_t maxLeaf, Bvh& out, float triC
   out.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
+void treeletLayout(Bvh& b) {
+  const uint32_t P = b.numNodes / 2;
+  if (P <= 2) return;
+  constexpr uint32_t NONE = 0xFFFFFFFFu, LINE = 4;
+  auto refOf = [&](uint32_t node) { uint32_t r; std::memcpy(&r, &b.nodes[(size_t)node * 8 + 3], 4); return r; };
+  auto internal = [](uint32_t ref) { return (ref >> BVH_COUNT_SHIFT) == 0; };
+  std::vector<uint32_t> newIdx(P, NONE), order;          // old pair -> new pair; new pair -> old pair (NONE: padding)
+  order.reserve((size_t)P + P / 4 + LINE);
+  std::vector<uint32_t> open[LINE];                     // open[f]: first free slot of lines with f slots left
+  order.assign(LINE, NONE); order[0] = 0; newIdx[0] = 0; open[LINE - 1].push_back(1);
+  std::vector<uint32_t> roots;                          // pairs that start a treelet, depth first
+  if (internal(b.rootRef)) roots.push_back(b.rootRef & BVH_INDEX_MASK);
+  std::vector<uint32_t> frontier;
+  while (!roots.empty()) {
+    const uint32_t r = roots.back(); roots.pop_back();
+    uint32_t g[LINE], n = 0;
+    frontier.clear(); frontier.push_back(r);
+    for (size_t at = 0; at < frontier.size() && n < LINE; at++) {
+      const uint32_t p = frontier[at];
+      g[n++] = p;
+      for (uint32_t k = 0; k < 2; k++) { uint32_t ref = refOf(2 * p + k); if (internal(ref)) frontier.push_back(ref & BVH_INDEX_MASK); }
+    }
+    for (size_t at = frontier.size(); at > n; at--) roots.push_back(frontier[at - 1]);     // left to right off the stack
+    uint32_t slot = NONE;
+    for (uint32_t f = n; f < LINE && slot == NONE; f++)
+      if (!open[f].empty()) {
+        slot = open[f].back(); open[f].pop_back();
+        if (f > n) open[f - n].push_back(slot + n);
+      }
+    if (slot == NONE) {
+      slot = (uint32_t)order.size(); order.resize(order.size() + LINE, NONE);
+      if (n < LINE) open[LINE - n].push_back(slot + n);
+    }
+    for (uint32_t i = 0; i < n; i++) { order[slot + i] = g[i]; newIdx[g[i]] = slot + i; }
+  }
+  std::vector<float> out(order.size() * 16);
+  for (size_t np = 0; np < order.size(); np++) {
+    float* dst = &out[np * 16];
+    if (order[np] == NONE) {
+      std::memcpy(dst, &b.nodes[0], 32); std::memcpy(dst + 8, &b.nodes[0], 32);
+      std::memcpy(dst + 3, &NONE, 4); std::memcpy(dst + 11, &NONE, 4);
+      continue;
+    }
+    std::memcpy(dst, &b.nodes[(size_t)order[np] * 16], 64);
+    if (np == 0) continue;                               // root box + padding: the root reference is set below
+    for (uint32_t k = 0; k < 2; k++) {
+      uint32_t ref; std::memcpy(&ref, dst + 8 * k + 3, 4);
+      if (internal(ref)) { ref = newIdx[ref & BVH_INDEX_MASK]; std::memcpy(dst + 8 * k + 3, &ref, 4); }
+    }
+  }
+  if (internal(b.rootRef)) { b.rootRef = newIdx[b.rootRef & BVH_INDEX_MASK]; std::memcpy(&out[3], &b.rootRef, 4); }
+  b.nodes.swap(out);
+  b.numNodes = (uint32_t)(b.nodes.size() / 8);
+}
+
 void quantizeNodes(const float* nodes, uint32_t numNodes, uint32_t* out, float qBase[3], float qScale[3]) {
   double cell[3], base[3];
   for (int k = 0; k < 3; k++) {

@@ -32,6 +32,13 @@ void quantizeNodes(const float* nodes, uint32_t numNodes, uint32_t* out, float q
 // The boxes the quantised tree stands for, in the layout of Bvh::nodes.
 void dequantizeNodes(const uint32_t* q, uint32_t numNodes, const float qBase[3], const float qScale[3], float* nodes);
 
+// Re-orders the sibling pairs for traversal from global memory: a 128-byte cache line holds four pairs of 16-byte
+// nodes, and after this every line holds a pair together with descendants of it (a treelet of up to four pairs, grown
+// breadth-first), so that the step after a line was fetched usually finds its pair in the same line.  Small treelets
+// share lines; slots left over hold unreferenced padding (ref = 0xFFFFFFFF).  Pair 0 (root box + padding) stays first.
+// Changes only where pairs lie and the references between them: the tree, and so every traversal result, is the same.
+void treeletLayout(Bvh& bvh);
+
 // v = T x 9 floats (v0, v1, v2).  Binned-SAH top-down build, leaves of at most maxLeaf triangles.  triCost: cost of a
 // triangle test relative to a step (one sibling pair): below 1 the tree gets fewer nodes and fuller leaves.
 void buildBvh(const float* v, uint32_t T, uint32_t maxLeaf, Bvh& out, float triCost = 1.0f);

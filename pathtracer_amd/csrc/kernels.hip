@@ -672,8 +672,74 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend(DevScene sc, DevCfg cfg, PixMap pm,
 // entries of its chunk (a new chunk from the pool when that is used up), until the queue is drained.  The traversal is
 // the postponed-leaf loop of traverseOct, resumable.  A ray's result does not depend on its lane or its companions.
 #ifndef PT_REFILL_BELOW
-#define PT_REFILL_BELOW 40
+#define PT_REFILL_BELOW 32
 #endif
+
+// A lane's ray and where its traversal of the (quantised, global-memory) tree stands.
+struct LaneTrav {
+  RayInv ri; V3 o, d; Hit h; bool found; uint32_t ref, leaf; int sp;
+  __device__ __forceinline__ bool busy() const { return ref != PT_NONE || leaf != PT_NONE; }
+};
+__device__ __forceinline__ void idleTrav(LaneTrav& t) {
+  t.ri = makeRayInv(v3(0, 0, 0), v3(1, 1, 1)); t.o = v3(0, 0, 0); t.d = v3(0, 0, 0);
+  t.h.t = PT_FLT_MAX; t.h.u = 0; t.h.v = 0; t.h.tri = 0xFFFFFFFFu; t.h.front = true; t.found = false;
+  t.ref = PT_NONE; t.leaf = PT_NONE; t.sp = 0;
+}
+__device__ __forceinline__ void startTrav(const DevScene& sc, LaneTrav& t, V3 o, V3 d) {
+  t.o = o; t.d = d;
+  t.ri = makeRayInv(o, d, v3(sc.qBase[0], sc.qBase[1], sc.qBase[2]));
+  // box planes come as grid coordinates q: plane = qBase + q * qScale
+  t.ri.a0x = fmaf(sc.qBase[0], t.ri.ix, t.ri.a0x); t.ri.a1x = fmaf(sc.qBase[0], t.ri.ix, t.ri.a1x); t.ri.ix = sc.qScale[0] * t.ri.ix;
+  t.ri.a0y = fmaf(sc.qBase[1], t.ri.iy, t.ri.a0y); t.ri.a1y = fmaf(sc.qBase[1], t.ri.iy, t.ri.a1y); t.ri.iy = sc.qScale[1] * t.ri.iy;
+  t.ri.a0z = fmaf(sc.qBase[2], t.ri.iz, t.ri.a0z); t.ri.a1z = fmaf(sc.qBase[2], t.ri.iz, t.ri.a1z); t.ri.iz = sc.qScale[2] * t.ri.iz;
+  t.h.t = PT_FLT_MAX; t.h.u = 0.0f; t.h.v = 0.0f; t.h.tri = 0xFFFFFFFFu; t.found = false;
+  t.sp = 0; t.ref = sc.rootRef; t.leaf = PT_NONE;
+  if (isLeaf(t.ref)) { t.leaf = t.ref; t.ref = PT_NONE; }
+}
+// Advances every lane's traversal until fewer than minBusy lanes are still at it (the postponed-leaf loop of
+// traverseOct, resumable; ANY: a lane stops at the first triangle it accepts).  Converged code.
+template <bool ANY>
+__device__ __forceinline__ void advanceTrav(const DevScene& sc, LaneTrav& t, uint32_t* stack, float eps, uint32_t minBusy) {
+  for (;;) {
+    if ((uint32_t)__popcll(__ballot(t.busy())) < minBusy) break;
+    while (isInternal(t.ref)) {
+      t.ref = stepDown<false, -1, ANY>(sc, t.ri, t.h.t, t.ref, stack, t.sp);
+      if (t.leaf == PT_NONE && isLeaf(t.ref)) { t.leaf = t.ref; t.ref = t.sp ? popRef(stack, t.sp) : PT_NONE; }
+      if (!__any(t.leaf == PT_NONE && t.ref != PT_NONE)) break;
+    }
+    while (t.leaf != PT_NONE) {
+      uint32_t cnt = t.leaf >> BVH_COUNT_SHIFT, first = t.leaf & BVH_INDEX_MASK;
+      bool stop = false;
+      for (uint32_t i = 0; i < cnt && !stop; i++) stop = testTriangle<ANY, false>(sc, (first + i) * 3, t.o, t.d, eps, t.h, t.found);
+      t.leaf = PT_NONE;
+      if (ANY && stop) { t.found = true; t.ref = PT_NONE; }
+      else if (isLeaf(t.ref)) { t.leaf = t.ref; t.ref = t.sp ? popRef(stack, t.sp) : PT_NONE; }
+    }
+  }
+}
+
+// The wave's share of a queue that is not handed to a lane yet, for the kernels whose lanes take a new entry when
+// theirs is done.  take(): flat index of the entry the lane gets (need: the lane wants one), or PT_NONE; false when
+// the queue is drained.  Converged code.
+struct WaveSupply {
+  uint32_t cb = 0, ce = 0, seg = 0; bool open = true;
+  __device__ __forceinline__ bool take(WorkPool* pool, uint32_t* counter, const QMeta& q, uint32_t total, uint32_t outLimit, bool need, uint32_t& j) {
+    j = PT_NONE;
+    if (cb == ce) {
+      Chunk ck;
+      // entries of this workgroup that are taken but not written out: at most a wave of rays and a chunk per wave
+      if (!nextChunk(pool, counter, q, total, outLimit, ck, 2u * blockDim.x)) { open = false; return false; }
+      cb = ck.begin; ce = ck.end; seg = ck.seg;
+    }
+    const unsigned long long m = __ballot(need);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    const uint32_t n = min((uint32_t)__popcll(m), ce - cb);
+    if (need && rank < n) j = cb + rank;
+    cb += n;
+    return true;
+  }
+};
+
 template <bool PRIMARY>
 __global__ void PT_TRAVERSAL_BOUNDS k_extend_refill(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, Wavefront wf) {
   __shared__ __align__(16) WorkPool pool;
@@ -687,72 +753,38 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend_refill(DevScene sc, DevCfg cfg, Pix
   const uint32_t outBase = segFirst * segCapOut, outLimit = (segLast - segFirst) * segCapOut;
   if (!PRIMARY && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&wf.stats[STAT_RAYS_INDIRECT], (unsigned long long)total);
   SegCursor cur; cur.seg = 0; cur.lo = 1; cur.hi = 0;
-  // the lane's ray and where its traversal stands
-  bool hasRay = false, found = false;
-  V3 o = v3(0, 0, 0), d = v3(0, 0, 0); uint32_t slot = 0; float carry = 0.0f;
-  RayInv ri = makeRayInv(v3(0, 0, 0), v3(1, 1, 1));
-  Hit h; h.t = PT_FLT_MAX; h.u = 0; h.v = 0; h.tri = 0xFFFFFFFFu; h.front = true;
-  uint32_t ref = PT_NONE, leaf = PT_NONE, stack[64]; int sp = 0;
-  // the wave's share of the queue that is not handed to a lane yet
-  uint32_t cb = 0, ce = 0, cseg = 0; bool supply = true;
+  bool hasRay = false; uint32_t slot = 0; float carry = 0.0f;
+  LaneTrav t; idleTrav(t);
+  uint32_t stack[64];
+  WaveSupply sup;
   for (;;) {
     bool need = !hasRay;
-    while (supply && __any(need)) {
-      if (cb == ce) {
-        Chunk ck;
-        // decided-but-unwritten and unstarted entries of this workgroup: at most a wave of rays and a chunk per wave
-        if (!nextChunk(&pool, wf.taskCounters, q, total, outLimit, ck, 2u * blockDim.x)) { supply = false; break; }
-        cb = ck.begin; ce = ck.end; cseg = ck.seg;
-      }
-      const unsigned long long m = __ballot(need);
-      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      const uint32_t n = min((uint32_t)__popcll(m), ce - cb);
-      if (need && rank < n) {
-        uint32_t e = physIndexHint(q, cb + rank, cseg, segCapIn, cur);
+    while (sup.open && __any(need)) {
+      uint32_t j;
+      if (!sup.take(&pool, wf.taskCounters, q, total, outLimit, need, j)) break;
+      if (j != PT_NONE) {
+        uint32_t e = physIndexHint(q, j, sup.seg, segCapIn, cur);
         if (PRIMARY) {
           float4 sd = wf.slotQ[e];
-          o = cfg.cam.pos; d = xyz(sd); slot = f2u(sd.w);
+          slot = f2u(sd.w); startTrav(sc, t, cfg.cam.pos, xyz(sd));
         } else {
           float4 ro = wf.rayO[e], rd = wf.rayD[e];
-          o = xyz(ro); d = xyz(rd); slot = f2u(ro.w); carry = rd.w;
+          slot = f2u(ro.w); carry = rd.w; startTrav(sc, t, xyz(ro), xyz(rd));
         }
-        ri = makeRayInv(o, d, v3(sc.qBase[0], sc.qBase[1], sc.qBase[2]));
-        ri.a0x = fmaf(sc.qBase[0], ri.ix, ri.a0x); ri.a1x = fmaf(sc.qBase[0], ri.ix, ri.a1x); ri.ix = sc.qScale[0] * ri.ix;
-        ri.a0y = fmaf(sc.qBase[1], ri.iy, ri.a0y); ri.a1y = fmaf(sc.qBase[1], ri.iy, ri.a1y); ri.iy = sc.qScale[1] * ri.iy;
-        ri.a0z = fmaf(sc.qBase[2], ri.iz, ri.a0z); ri.a1z = fmaf(sc.qBase[2], ri.iz, ri.a1z); ri.iz = sc.qScale[2] * ri.iz;
-        h.t = PT_FLT_MAX; h.u = 0.0f; h.v = 0.0f; h.tri = 0xFFFFFFFFu; found = false;
-        sp = 0; ref = sc.rootRef; leaf = PT_NONE;
-        if (isLeaf(ref)) { leaf = ref; ref = PT_NONE; }
         hasRay = true; need = false;
       }
-      cb += n;
     }
     if (!__any(hasRay)) break;
-    const uint32_t minBusy = supply ? (uint32_t)PT_REFILL_BELOW : 1u;
-    for (;;) {
-      const bool busy = ref != PT_NONE || leaf != PT_NONE;
-      if ((uint32_t)__popcll(__ballot(busy)) < minBusy) break;
-      while (isInternal(ref)) {
-        ref = stepDown<false, -1, false>(sc, ri, h.t, ref, stack, sp);
-        if (leaf == PT_NONE && isLeaf(ref)) { leaf = ref; ref = sp ? popRef(stack, sp) : PT_NONE; }
-        if (!__any(leaf == PT_NONE && ref != PT_NONE)) break;
-      }
-      while (leaf != PT_NONE) {
-        uint32_t cnt = leaf >> BVH_COUNT_SHIFT, first = leaf & BVH_INDEX_MASK;
-        for (uint32_t i = 0; i < cnt; i++) testTriangle<false, false>(sc, (first + i) * 3, o, d, cfg.eps, h, found);
-        leaf = PT_NONE;
-        if (isLeaf(ref)) { leaf = ref; ref = sp ? popRef(stack, sp) : PT_NONE; }
-      }
-    }
-    const bool fin = hasRay && ref == PT_NONE && leaf == PT_NONE;
-    const bool isHit = fin && found;
+    advanceTrav<false>(sc, t, stack, cfg.eps, sup.open ? (uint32_t)PT_REFILL_BELOW : 1u);
+    const bool fin = hasRay && !t.busy();
+    const bool isHit = fin && t.found;
     uint32_t idx = waveAppend(isHit, &pool.out);
     if (isHit) {
       uint32_t e = outBase + idx;
-      wf.hitA[e] = f4(o + d * h.t, u2f(h.tri));
-      wf.hitB[e] = make_float4(h.u, h.v, u2f(slot), PRIMARY ? h.t : carry);
+      wf.hitA[e] = f4(t.o + t.d * t.h.t, u2f(t.h.tri));
+      wf.hitB[e] = make_float4(t.h.u, t.h.v, u2f(slot), PRIMARY ? t.h.t : carry);
     } else if (fin && PRIMARY) {
-      wf.Lacc[slot] = f4(sampleSky(d), 0.0f);
+      wf.Lacc[slot] = f4(sampleSky(t.d), 0.0f);
     }
     if (fin) hasRay = false;
   }
@@ -763,6 +795,10 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend_refill(DevScene sc, DevCfg cfg, Pix
     wf.hitQ.count[s] = n > before ? min(n - before, segCapOut) : 0u;
   }
 }
+
+// (The same scheme in k_connect and k_occluded was measured on the 10 M-triangle soup and dropped: 25.5 -> 27.1 ms and
+// 28.2 -> 28.3 ms per 4 spp.  Their rays start at scattered hit points, half of their node and triangle fetches miss
+// the L2, and the launches move 0.6-0.7 of the HBM peak: memory, not idle lanes, is what they wait for.)
 
 // View rays generated in registers, no cull, no queue: the parity probe (getViewRay without jitter + Scene.trace).
 template <bool LDSS, bool COUNT>

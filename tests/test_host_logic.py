@@ -354,9 +354,9 @@ def test_quantised_nodes_contain_their_boxes(name, flats):
     """Scenes traversed from global memory get 16-byte nodes on a 16-bit grid over the root box: every box returned for
     such a scene contains the float box of the same node, by no more than a few grid cells, and the tree is the same."""
     if name == 'soup':
-        fl = soup(3000, seed=11); a = host_tracer(flat=fl); b = host_tracer(flat=fl, flags=P.PT_FLAG_NO_LDS_SCENE)
+        fl = soup(3000, seed=11); a = host_tracer(flat=fl, flags=P.PT_FLAG_NO_TREELETS); b = host_tracer(flat=fl, flags=P.PT_FLAG_NO_LDS_SCENE | P.PT_FLAG_NO_TREELETS)
     else:
-        a = host_tracer(name); b = host_tracer(name, flags=P.PT_FLAG_NO_LDS_SCENE)
+        a = host_tracer(name); b = host_tracer(name, flags=P.PT_FLAG_NO_LDS_SCENE | P.PT_FLAG_NO_TREELETS)
     assert b.stats().sceneInLds == 0
     (na, oa), (nb, ob) = a.get_bvh(), b.get_bvh()
     assert np.array_equal(oa, ob) and np.array_equal(na[:, 3].view(np.uint32), nb[:, 3].view(np.uint32))
@@ -367,3 +367,38 @@ def test_quantised_nodes_contain_their_boxes(name, flats):
     assert (mn_b <= mn_a).all() and (mx_b >= mx_a).all()
     cell = (na[0, 4:7] - na[0, 0:3]) / 65529.0
     assert ((mn_a - mn_b) <= 3.01 * cell + 1e-30).all() and ((mx_b - mx_a) <= 3.01 * cell + 1e-30).all()
+
+
+@pytest.mark.parametrize('name', ['teapot', 'soup'])
+def test_cache_line_layout_of_the_node_pairs_keeps_the_tree(name, flats):
+    """Scenes traversed from global memory: sibling pairs are re-ordered so that a 128-byte line (four pairs of 16-byte
+    nodes) holds a pair together with descendants.  The tree is the same -- walked from the root in step with the
+    builder's order, every box and every leaf agrees -- most steps down land in the line of the pair they come from,
+    and few slots are padding."""
+    if name == 'soup':
+        fl = soup(20000, seed=5)
+        a = host_tracer(flat=fl, flags=P.PT_FLAG_NO_LDS_SCENE | P.PT_FLAG_NO_TREELETS); b = host_tracer(flat=fl, flags=P.PT_FLAG_NO_LDS_SCENE)
+    else:
+        a = host_tracer(name, flags=P.PT_FLAG_NO_LDS_SCENE | P.PT_FLAG_NO_TREELETS); b = host_tracer(name, flags=P.PT_FLAG_NO_LDS_SCENE)
+    (na, oa), (nb, ob) = a.get_bvh(), b.get_bvh()
+    assert np.array_equal(oa, ob)
+    ra, rb = na[:, 3].view(np.uint32), nb[:, 3].view(np.uint32)
+    assert len(nb) % 8 == 0 and len(nb) >= len(na)
+    stack = [(int(ra[0]), int(rb[0]), 0)]
+    pairs = same_line = 0
+    seen = set()
+    while stack:
+        x, y, parent = stack.pop()
+        assert (x >> 28) == (y >> 28)
+        if x >> 28:
+            assert x == y                                            # same leaf: same triangles
+            continue
+        assert y not in seen; seen.add(y)
+        pairs += 1; same_line += (y // 4 == parent // 4)
+        for k in (0, 1):
+            assert np.array_equal(na[2 * x + k, [0, 1, 2, 4, 5, 6]], nb[2 * y + k, [0, 1, 2, 4, 5, 6]])
+            stack.append((int(ra[2 * x + k]), int(rb[2 * y + k]), y))
+    assert pairs == len(na) // 2 - 1                                 # every pair of the original, once
+    unused = rb.reshape(-1, 2)[:, 0] == 0xFFFFFFFF
+    assert int((~unused).sum()) == pairs + 1 and unused.mean() < 0.2
+    assert same_line / pairs > 0.5                                   # at most 3 of 4: the first pair of a line comes from another
