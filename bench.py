@@ -46,6 +46,7 @@ EXTRA_AT_ONE_GPU = ('c2_teapot_1080p_256spp', 'c1_cornell_512_16spp')
 # operations: 256 CUs x 4 SIMDs x 32 lanes per cycle at 2.4 GHz
 HBM_PEAK_GBS = 8000.0
 LDS_PEAK_GBS = 150000.0
+L2_PEAK_GBS = 34500.0                  # aggregate of the eight 4 MiB L2s (micro-architecture guide)
 VALU_PEAK_GLANEOPS = 256 * 4 * 32 * 2.4
 # algorithmic bytes (defined on the canonical layout: 32-byte node, 9 floats per triangle)
 B_STREAM_CLOSEST, B_STREAM_ANY, B_NODE, B_TRI = 48.0, 36.0, 32.0, 36.0
@@ -131,13 +132,21 @@ def ceilings(kind, st, visits, ms, launches, pmc, scene_in_lds):
     else:
         return None
     scene_bytes = nodes * B_NODE + tris * B_TRI
-    hbm_bytes = stream + (0.0 if scene_in_lds else scene_bytes)
+    # What must cross HBM whatever the caches do: the queue records.  The nodes and triangles of a scene in global
+    # memory are re-read by every ray and served by L2 and the Infinity Cache as far as they reach: their algorithmic
+    # bytes are held against the L2's bandwidth (they would exceed the HBM peak: on the soup 8.6 TB/s), and what
+    # really reaches HBM is the measured figure of the counter pass below.
+    hbm_bytes = stream
     out = {'units_per_launch': round(rays / launches, 1), 'avg_launch_us': round(1e3 * ms / launches, 3),
            'hbm': {'algorithmic_bytes_per_launch': round(hbm_bytes / launches, 1), 'achieved_GBps': round(hbm_bytes / sec / 1e9, 2),
                    'frac': round(hbm_bytes / sec / 1e9 / HBM_PEAK_GBS, 5)}}
     if scene_in_lds and scene_bytes:
         out['lds'] = {'algorithmic_bytes_per_launch': round(scene_bytes / launches, 1), 'achieved_GBps': round(scene_bytes / sec / 1e9, 2),
                       'frac': round(scene_bytes / sec / 1e9 / LDS_PEAK_GBS, 5)}
+    elif scene_bytes:
+        l2_bytes = stream + scene_bytes
+        out['l2'] = {'algorithmic_bytes_per_launch': round(l2_bytes / launches, 1), 'achieved_GBps': round(l2_bytes / sec / 1e9, 2),
+                     'frac': round(l2_bytes / sec / 1e9 / L2_PEAK_GBS, 5)}
     k = (pmc.get('kinds') or {}).get(kind)
     if k:
         if k.get('hbm_bytes_per_launch'):
@@ -247,19 +256,20 @@ def measure(P, torch, dist, multigpu, name, args, rank, world, local_rank, rehea
     # the dominant kernel: the kind with the largest summed time; its binding ceiling heads the roofline object
     dom = max(ceil, key=lambda k: kern[k]['total_ms'])
     d = ceil[dom]
-    fr = {k: d[k]['frac'] for k in ('hbm', 'lds', 'valu') if k in d}
+    fr = {k: d[k]['frac'] for k in ('hbm', 'lds', 'l2', 'valu') if k in d}
     bound = max(fr, key=fr.get)
     if bound == 'valu':
         achieved, peak, unit = d['valu']['achieved_Glaneops'], VALU_PEAK_GLANEOPS, 'Glaneop/s'
     else:
-        achieved, peak, unit = d[bound]['achieved_GBps'], (HBM_PEAK_GBS if bound == 'hbm' else LDS_PEAK_GBS), 'GB/s'
+        achieved, peak, unit = d[bound]['achieved_GBps'], {'hbm': HBM_PEAK_GBS, 'lds': LDS_PEAK_GBS, 'l2': L2_PEAK_GBS}[bound], 'GB/s'
     roofline = dict(bound=bound, achieved=achieved, peak=peak, unit=unit, frac=fr[bound],
                     traffic=d['hbm'].get('measured_bytes_per_launch'), kernel=dom, launches=kern[dom]['launches'],
                     avg_launch_us=kern[dom]['avg_us'],
                     traffic_source=(pmc_src + ' (rocprofv3 --pmc passes of the same command, read from the committed file: the counters '
                                     'need profiler processes of their own)') if pmc_src and d['hbm'].get('measured_bytes_per_launch') else None,
                     definition='frac = achieved / peak of the binding ceiling of the dominant kernel; hbm: algorithmic bytes that must '
-                               'cross HBM / launch time / 8 TB/s; lds: node + triangle bytes served from the scene copy in LDS / 150 TB/s; '
+                               'cross HBM (queue records) / launch time / 8 TB/s; lds: node + triangle bytes served from the scene copy in LDS / 150 TB/s; '
+                               'l2 (scene in global memory): records + node + triangle bytes / 34.5 TB/s; '
                                'valu: vector instructions x 2 cycles / SIMD cycles x active-lane fraction (PMC)',
                     bytes_per_ray=dict(closest=round(B_STREAM_CLOSEST + visits['nodes_closest'] * B_NODE + visits['tris_closest'] * B_TRI, 2),
                                        any=round(B_STREAM_ANY + visits['nodes_any'] * B_NODE + visits['tris_any'] * B_TRI, 2)),

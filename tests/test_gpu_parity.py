@@ -288,6 +288,7 @@ def test_visit_counters_match_cpu_restatement_of_the_traversal(require_gpu, flat
     for flags, order_rule in ((P.PT_FLAG_COUNT_VISITS, 2), (P.PT_FLAG_COUNT_VISITS | P.PT_FLAG_NO_LDS_SCENE, 1)):
         pa = make_tracer(name, W, H, flags=flags)
         nodes, order = pa.get_bvh()
+        root = int(nodes[0, 3:4].view(np.uint32)[0])             # (the node pairs of a scene in global memory are laid out anew)
         pa.reset_stats(); free = pa.hitsNothing(rays)
         st = pa.stats()
         n_nodes, n_tris, tri = o.bvh_count(nodes, root, order, rays, any_hit=order_rule)
