@@ -31,6 +31,10 @@ def parse(path):
 
 
 def kind_of(name):
+    if name.startswith('k_extend_refill<'):
+        return 'extend'
+    if name.startswith('k_shade_traced<') or name.startswith('k_sample_traced'):
+        return 'shade'                                      # shading that traces its own rays; the whole-sample kernel
     for k in ('extend', 'connect', 'occluded', 'shade', 'accumulate', 'raygen'):
         if name.startswith('k_' + k + '<') or name == 'k_' + k:
             if k in ('extend', 'connect', 'occluded') and name.rstrip().endswith(', true>'):
