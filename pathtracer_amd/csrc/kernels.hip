@@ -154,6 +154,11 @@ struct Hit { float t, u, v; uint32_t tri; bool front; };
 #ifndef PT_FUSE_OCTANTS
 #define PT_FUSE_OCTANTS false
 #endif
+// Diagnostic builds (scripts/build_variant.sh <tag> -D...; never defined in the library that ships):
+//   PT_STAMP / PT_SLOTS   the counting variants report wave clock ticks / lane slots of the descent loop instead of visits
+//   PT_PROBE_HALF=n       extend gives a wave n rays instead of 64 (what part of a launch depends on busy lanes)
+//   PT_PROBE_A / _B / _C  the traced shading without its chain traversals / its chain loop / its sun and sky traversals
+//                         (wrong images: timing only)
 #if defined(PT_STAMP) || defined(PT_SLOTS)
 #define PT_STAMP_ON 1
 #else
