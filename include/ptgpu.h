@@ -158,7 +158,9 @@ int ptgpu_camera_look_at(PtHandle* h, float fovDegrees, float aspect, const floa
 
 /* computeOutputColor(pixelOffset, pixels[0..pixelCount], gen) repeated spp times (rendering.d:494-500):
  * every pixel of the window gets spp more samples; sum += L, n += 1, color = sum / n.  Asynchronous on
- * the handle's stream. */
+ * the handle's stream, with two exceptions: the first call after the scene or the camera changed builds the view-ray
+ * masks on the GPU and waits for that build once (PtStats.maskBuildMs: 1-4 ms), and the first call of a new batch shape
+ * allocates the batch state.  ptgpu_render_noalloc does neither allocation nor, once the masks exist, any waiting. */
 int ptgpu_render(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount, uint32_t spp);
 /* The reference's task decomposition (main.d:184-192) as one call: renders the scanline bands
  * b = bandFirst, bandFirst + bandStride, ... (band = bandRows rows) -- the per-GPU share of a frame. */
