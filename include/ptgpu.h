@@ -76,10 +76,9 @@ typedef struct PtConfig {
                                      tables together fit in 24 KB of LDS, shading traces the rays it spawns itself --
                                      light-sample rays, sun / sky rays, continuation rays of the indirect chains --
                                      instead of queueing them; same rays, same results)                            */
-#define PT_FLAG_QUEUED_VIEW_RAYS 256u /* with traced shading: always keep raygen, extend and shade as separate launches for
-                                     the view rays (default: batches of 32 Mi samples or more generate a sample's view
-                                     ray, trace it and shade its hit in one kernel)                                  */
-#define PT_FLAG_WHOLE_SAMPLE_KERNEL 512u /* with traced shading: that one kernel whatever the batch size             */
+#define PT_FLAG_QUEUED_VIEW_RAYS 256u /* with traced shading: keep raygen, extend and shade as separate launches for the
+                                     view rays (default: one kernel generates a sample's view ray, traces it and shades
+                                     its hit)                                                                        */
 #define PT_FLAG_NO_TREELETS 1024u   /* scenes traversed from global memory: keep the builder's order of the node pairs
                                      (default: pairs are laid out so that a 128-byte line holds a pair with
                                      descendants of it)                                                              */

@@ -496,11 +496,7 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
   };
   uint32_t nslots = pm.npix * pm.k;
   h->st.raysPrimary += nslots; h->st.samples += nslots;
-  // Large batches only: the one launch saves the view rays' queue traffic (cornell 3840x2160, 64 spp: 42.5 -> 35.3 ms),
-  // but its waves run a sample's whole dependent chain at 6 waves per SIMD, and a batch of a few million samples is done
-  // sooner by the three specialised launches (cornell 512x512, 16 spp: 0.57 vs 0.73 ms)
-  const bool wholeSample = wf.fuse && !(h->cfg.flags & PT_FLAG_QUEUED_VIEW_RAYS) &&
-                           ((h->cfg.flags & PT_FLAG_WHOLE_SAMPLE_KERNEL) || nslots >= PT_WHOLE_SAMPLE_MIN_SLOTS);
+  const bool wholeSample = wf.fuse && !(h->cfg.flags & PT_FLAG_QUEUED_VIEW_RAYS);
   if (wholeSample) {
     // raygen, the view rays and the shading of their hits in one launch; it appends what stage 1's shade would
     bind(1);
@@ -681,7 +677,7 @@ int ptgpu_create(const PtConfig* cfg, PtHandle** out) {
     h->accBytes = (uint64_t)c.width * c.height * 16;
     h->accOwn.alloc(h->accBytes); h->acc = h->accOwn.as<float4>();
     HIPCHECK(hipMemset(h->acc, 0, h->accBytes));
-    h->bStats.alloc(STAT_COUNT * 8); HIPCHECK(hipMemset(h->bStats.p, 0, STAT_COUNT * 8));
+    h->bStats.alloc(PT_STAT_REPLICAS * PT_STAT_STRIDE * 8); HIPCHECK(hipMemset(h->bStats.p, 0, h->bStats.bytes));
     HIPCHECK(hipStreamCreateWithFlags(&h->copyStream, hipStreamNonBlocking));
     for (int k = 0; k < 2; k++) {
       HIPCHECK(hipEventCreateWithFlags(&h->evTone[k], hipEventDisableTiming));
@@ -1238,8 +1234,10 @@ int ptgpu_get_stats(PtHandle* h, PtStats* out) {
     useDevice(h);
     HIPCHECK(hipStreamSynchronize(h->stream));
     resolveEvents(h);
-    unsigned long long s[STAT_COUNT];
-    HIPCHECK(hipMemcpy(s, h->bStats.p, sizeof(s), hipMemcpyDeviceToHost));
+    unsigned long long all[PT_STAT_REPLICAS * PT_STAT_STRIDE], s[STAT_COUNT] = {};
+    HIPCHECK(hipMemcpy(all, h->bStats.p, sizeof(all), hipMemcpyDeviceToHost));
+    for (int r = 0; r < PT_STAT_REPLICAS; r++)
+      for (int k = 0; k < STAT_COUNT; k++) s[k] += all[r * PT_STAT_STRIDE + k];
     h->st.raysLight = s[STAT_RAYS_LIGHT]; h->st.raysIndirect = s[STAT_RAYS_INDIRECT]; h->st.raysOcclusion = s[STAT_RAYS_OCCL];
     h->st.nodesClosest = s[STAT_NODES_CLOSEST]; h->st.trisClosest = s[STAT_TRIS_CLOSEST];
     h->st.nodesAny = s[STAT_NODES_ANY]; h->st.trisAny = s[STAT_TRIS_ANY]; h->st.raysCulled = s[STAT_RAYS_CULLED];
@@ -1255,7 +1253,7 @@ int ptgpu_reset_stats(PtHandle* h) {
     useDevice(h);
     HIPCHECK(hipStreamSynchronize(h->stream));
     resolveEvents(h);
-    HIPCHECK(hipMemset(h->bStats.p, 0, STAT_COUNT * 8));
+    HIPCHECK(hipMemset(h->bStats.p, 0, h->bStats.bytes));
     PtStats keep = h->st; h->st = PtStats();
     h->st.numTriangles = keep.numTriangles; h->st.numNodes = keep.numNodes; h->st.bvhDepth = keep.bvhDepth;
     h->st.numLightGroups = keep.numLightGroups; h->st.sceneInLds = keep.sceneInLds;

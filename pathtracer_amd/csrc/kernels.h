@@ -162,12 +162,12 @@ struct Wavefront {
 
 // Scene and tables of the fused shading variant share a shade workgroup's LDS; above this the general path runs.
 constexpr uint32_t PT_FUSE_LDS_BYTES = 24 * 1024;
-// Batches from this many samples up run raygen, view-ray trace and the shading of view-ray hits as one kernel.
-constexpr uint32_t PT_WHOLE_SAMPLE_MIN_SLOTS = 1u << 25;
 
 enum { STAT_RAYS_LIGHT = 0, STAT_RAYS_INDIRECT, STAT_RAYS_OCCL, STAT_NODES_CLOSEST, STAT_TRIS_CLOSEST,
        STAT_NODES_ANY, STAT_TRIS_ANY, STAT_RAYS_CULLED, STAT_HITS, STAT_ENV_ENTRIES, STAT_FUSED_INDIRECT, STAT_FUSED_OCCL, STAT_HITS_PRIMARY, STAT_FUSED_LIGHT, STAT_FUSED_PRIMARY,
        STAT_COUNT };
+constexpr int PT_STAT_REPLICAS = 64, PT_STAT_STRIDE = 16;   // copies of the counters, 128 B apart (kernels.hip: statAdd)
+static_assert(STAT_COUNT <= PT_STAT_STRIDE, "a copy of the counters is one 128-byte line");
 
 // Workgroups of a traversal kernel per CU when the scene copy in LDS takes `bytes` (0: it does not fit at all).
 inline uint32_t ldsWorkgroupsPerCU(uint64_t bytes) {

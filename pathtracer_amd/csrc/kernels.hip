@@ -43,6 +43,13 @@ extern __shared__ float4 g_lds[];   // [0, 2*numNodes) nodes, then 3*numTris tri
 namespace {
 
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+// Counters are kept in PT_STAT_REPLICAS copies, each on a cache line of its own, and a workgroup adds to the copy of
+// its index: thousands of waves adding to ONE word at the end of a launch queue up behind each other (a word takes
+// fewer than 10^8 atomic adds a second -- half a millisecond for a launch of 8192 waves with six counters, more than
+// the rest of a small pass).  ptgpu_get_stats sums the copies.
+__device__ __forceinline__ void statAdd(unsigned long long* stats, int which, unsigned long long v) {
+  atomicAdd(&stats[(blockIdx.x % PT_STAT_REPLICAS) * PT_STAT_STRIDE + which], v);
+}
 __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ V3 xyz(float4 a) { return v3(a.x, a.y, a.z); }
 __device__ __forceinline__ float4 f4(V3 a, float w) { return make_float4(a.x, a.y, a.z, w); }
@@ -371,7 +378,7 @@ __device__ __forceinline__ bool traverse(const DevScene& sc, V3 o, V3 d, float e
 template <bool COUNT> __device__ __forceinline__ void flushCounts(unsigned long long* stats, int nodeSlot, uint32_t cN, uint32_t cT) {
   if constexpr (COUNT) {
     for (int off = 32; off > 0; off >>= 1) { cN += __shfl_down(cN, off); cT += __shfl_down(cT, off); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[nodeSlot], (unsigned long long)cN); atomicAdd(&stats[nodeSlot + 1], (unsigned long long)cT); }
+    if ((threadIdx.x & 63) == 0) { statAdd(stats, nodeSlot, (unsigned long long)cN); statAdd(stats, nodeSlot + 1, (unsigned long long)cT); }
   }
 }
 
@@ -603,7 +610,7 @@ __global__ void __launch_bounds__(PT_RAYGEN_THREADS) k_raygen(SceneBox box, View
     }
   }
   for (int off = 32; off > 0; off >>= 1) culled += __shfl_down(culled, off);
-  if ((threadIdx.x & 63) == 0 && culled) atomicAdd(&wf.stats[STAT_RAYS_CULLED], (unsigned long long)culled);
+  if ((threadIdx.x & 63) == 0 && culled) statAdd(wf.stats, STAT_RAYS_CULLED, (unsigned long long)culled);
   __syncthreads();
   if (threadIdx.x == 0) wf.rayOut.count[T] = sCnt;
 }
@@ -627,7 +634,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend(DevScene sc, DevCfg cfg, PixMap pm,
   const uint32_t segFirst = (uint32_t)(((uint64_t)blockIdx.x * PT_SEGS) / gridDim.x);
   const uint32_t segLast = (uint32_t)(((uint64_t)(blockIdx.x + 1) * PT_SEGS) / gridDim.x);
   const uint32_t outBase = segFirst * segCapOut, outLimit = (segLast - segFirst) * segCapOut;
-  if (!PRIMARY && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&wf.stats[STAT_RAYS_INDIRECT], (unsigned long long)total);
+  if (!PRIMARY && blockIdx.x == 0 && threadIdx.x == 0) statAdd(wf.stats, STAT_RAYS_INDIRECT, (unsigned long long)total);
   SegCursor cur; cur.seg = 0; cur.lo = 1; cur.hi = 0;      // empty: the first entry searches
   Chunk ck;
   while (nextChunk(&pool, wf.taskCounters, q, total, outLimit, ck)) {
@@ -756,7 +763,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend_refill(DevScene sc, DevCfg cfg, Pix
   const uint32_t segFirst = (uint32_t)(((uint64_t)blockIdx.x * PT_SEGS) / gridDim.x);
   const uint32_t segLast = (uint32_t)(((uint64_t)(blockIdx.x + 1) * PT_SEGS) / gridDim.x);
   const uint32_t outBase = segFirst * segCapOut, outLimit = (segLast - segFirst) * segCapOut;
-  if (!PRIMARY && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&wf.stats[STAT_RAYS_INDIRECT], (unsigned long long)total);
+  if (!PRIMARY && blockIdx.x == 0 && threadIdx.x == 0) statAdd(wf.stats, STAT_RAYS_INDIRECT, (unsigned long long)total);
   SegCursor cur; cur.seg = 0; cur.lo = 1; cur.hi = 0;
   bool hasRay = false; uint32_t slot = 0; float carry = 0.0f;
   LaneTrav t; idleTrav(t);
@@ -870,7 +877,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_connect(DevScene sc, float eps, QMeta q, u
   __syncthreads();
   uint32_t cN = 0, cT = 0;
   const uint32_t total = q.prefix[PT_SEGS];
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[STAT_RAYS_LIGHT], (unsigned long long)total);
+  if (blockIdx.x == 0 && threadIdx.x == 0) statAdd(stats, STAT_RAYS_LIGHT, (unsigned long long)total);
   SegCursor cur; cur.seg = 0; cur.lo = 1; cur.hi = 0;      // empty: the first entry searches
   Chunk ck;
   while (nextChunk(&pool, taskCounter, q, total, 0, ck)) {
@@ -919,7 +926,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_occluded(DevScene sc, float eps, V3 sunRad
   __syncthreads();
   uint32_t cN = 0, cT = 0, nRays = 0;
   const uint32_t total = q.prefix[PT_SEGS];
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[STAT_ENV_ENTRIES], (unsigned long long)total);
+  if (blockIdx.x == 0 && threadIdx.x == 0) statAdd(stats, STAT_ENV_ENTRIES, (unsigned long long)total);
   SegCursor cur; cur.seg = 0; cur.lo = 1; cur.hi = 0;      // empty: the first entry searches
   Chunk ck;
   while (nextChunk(&pool, taskCounter, q, total, 0, ck)) {
@@ -949,7 +956,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_occluded(DevScene sc, float eps, V3 sunRad
     }
   }
   for (int off = 32; off > 0; off >>= 1) nRays += __shfl_down(nRays, off);
-  if ((threadIdx.x & 63) == 0 && nRays) atomicAdd(&stats[STAT_RAYS_OCCL], (unsigned long long)nRays);
+  if ((threadIdx.x & 63) == 0 && nRays) statAdd(stats, STAT_RAYS_OCCL, (unsigned long long)nRays);
   flushCounts<COUNT>(stats, STAT_NODES_ANY, cN, cT);
 }
 
@@ -1236,10 +1243,10 @@ __device__ __forceinline__ void flushTraced(ShadeCtx& cx) {
   }
   if ((threadIdx.x & 63) == 0) {
     unsigned long long* st = cx.wf.stats;
-    if (nLight) { atomicAdd(&st[STAT_RAYS_LIGHT], (unsigned long long)nLight); atomicAdd(&st[STAT_FUSED_LIGHT], (unsigned long long)nLight); }
-    if (nInd) { atomicAdd(&st[STAT_RAYS_INDIRECT], (unsigned long long)nInd); atomicAdd(&st[STAT_FUSED_INDIRECT], (unsigned long long)nInd); }
-    if (nOccl) { atomicAdd(&st[STAT_RAYS_OCCL], (unsigned long long)nOccl); atomicAdd(&st[STAT_FUSED_OCCL], (unsigned long long)nOccl); }
-    if (nEnv) atomicAdd(&st[STAT_ENV_ENTRIES], (unsigned long long)nEnv);
+    if (nLight) { statAdd(st, STAT_RAYS_LIGHT, (unsigned long long)nLight); statAdd(st, STAT_FUSED_LIGHT, (unsigned long long)nLight); }
+    if (nInd) { statAdd(st, STAT_RAYS_INDIRECT, (unsigned long long)nInd); statAdd(st, STAT_FUSED_INDIRECT, (unsigned long long)nInd); }
+    if (nOccl) { statAdd(st, STAT_RAYS_OCCL, (unsigned long long)nOccl); statAdd(st, STAT_FUSED_OCCL, (unsigned long long)nOccl); }
+    if (nEnv) statAdd(st, STAT_ENV_ENTRIES, (unsigned long long)nEnv);
   }
 }
 
@@ -1261,8 +1268,8 @@ __device__ __forceinline__ void shadeBody(const DevScene& sc, const DevCfg& cfg,
   SegCursor seg = segCursor(wf.hitQ, tk.seg);
   const FastDiv divCap = wf.divCap;
   if (T == 0 && threadIdx.x == 0) {
-    atomicAdd(&wf.stats[STAT_HITS], (unsigned long long)wf.hitQ.prefix[PT_SEGS]);
-    if (PRIMARY) atomicAdd(&wf.stats[STAT_HITS_PRIMARY], (unsigned long long)wf.hitQ.prefix[PT_SEGS]);
+    statAdd(wf.stats, STAT_HITS, (unsigned long long)wf.hitQ.prefix[PT_SEGS]);
+    if (PRIMARY) statAdd(wf.stats, STAT_HITS_PRIMARY, (unsigned long long)wf.hitQ.prefix[PT_SEGS]);
   }
   for (uint32_t base = tk.begin; base < tk.end; base += blockDim.x) {
     uint32_t j = base + threadIdx.x;
@@ -1330,7 +1337,7 @@ __global__ void __launch_bounds__(PT_FUSE_THREADS, PT_FUSE_WAVES) k_sample_trace
   tb.stage();
   __syncthreads();
   // Runs of 64 slots (one wave: a tile of pixels at one sample number) are dealt out to the block-tasks in turn, run c
-  // to task c % PT_SEGS, and a task's runs to its waves in turn: the work of a run ranges from nothing (sky) to a
+  // to task c % PT_SEGS, and a task's runs to its waves as they become free: the work of a run ranges from nothing (sky) to a
   // vertex with all its rays, and contiguous shares would leave the tasks that cover background idle.  A task gets at
   // most capSlots / (64 * PT_SEGS) runs, so what it appends fits its segment.  Waves do not wait for each other.
   const uint32_t T = blockIdx.x, runs = (nslots + 63u) >> 6;
@@ -1338,7 +1345,15 @@ __global__ void __launch_bounds__(PT_FUSE_THREADS, PT_FUSE_WAVES) k_sample_trace
   ShadeCtx cx{sc, cfg, wf, sCnt, T, segCap, segCap};
   cx.segCapHit = wf.capHit / PT_SEGS;
   uint32_t culled = 0, hits = 0, mine = 0;
-  for (uint32_t run = T + PT_SEGS * (threadIdx.x >> 6); run < runs; run += PT_SEGS * (blockDim.x >> 6)) {
+  // a task's runs go to whichever of its waves is free next
+  __shared__ uint32_t sNextRun;
+  if (threadIdx.x == 0) sNextRun = 0;
+  __syncthreads();
+  for (;;) {
+    uint32_t k = 0;
+    if ((threadIdx.x & 63u) == 0) k = atomicAdd(&sNextRun, 1u);
+    const uint32_t run = T + PT_SEGS * (uint32_t)__builtin_amdgcn_readfirstlane(k);
+    if (run >= runs) break;
     const uint32_t i = (run << 6) + (threadIdx.x & 63u);
     const bool valid = i < nslots;
     if (valid) mine++;
@@ -1375,11 +1390,11 @@ __global__ void __launch_bounds__(PT_FUSE_THREADS, PT_FUSE_WAVES) k_sample_trace
   flushTraced(cx);
   for (int off = 32; off > 0; off >>= 1) { culled += __shfl_down(culled, off); hits += __shfl_down(hits, off); mine += __shfl_down(mine, off); }
   if ((threadIdx.x & 63) == 0) {
-    if (culled) atomicAdd(&wf.stats[STAT_RAYS_CULLED], (unsigned long long)culled);
+    if (culled) statAdd(wf.stats, STAT_RAYS_CULLED, (unsigned long long)culled);
     if (hits) {
-      atomicAdd(&wf.stats[STAT_HITS], (unsigned long long)hits); atomicAdd(&wf.stats[STAT_HITS_PRIMARY], (unsigned long long)hits);
+      statAdd(wf.stats, STAT_HITS, (unsigned long long)hits); statAdd(wf.stats, STAT_HITS_PRIMARY, (unsigned long long)hits);
     }
-    if (mine > culled) atomicAdd(&wf.stats[STAT_FUSED_PRIMARY], (unsigned long long)(mine - culled));     // view rays traced here
+    if (mine > culled) statAdd(wf.stats, STAT_FUSED_PRIMARY, (unsigned long long)(mine - culled));     // view rays traced here
   }
   __syncthreads();
   if (threadIdx.x == 0) wf.rayOut.count[T] = sCnt[0];
