@@ -518,6 +518,12 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
     fusedStage(1, true, false);
     if (dc.mode == 1)
       for (uint32_t round = 0; round <= dc.maxDepth; round++) fusedStage(round + 2, false, round == dc.maxDepth);
+  } else if (dc.mode == 0 && envDirect(dc, h->dsc, true) && !lc.countVisits && !(h->cfg.flags & PT_FLAG_NO_FUSE)) {
+    // a vertex spawns nothing but its sun and sky ray: the kernel that traces them shades the hit itself
+    bind(1);
+    { Timed t(h, PT_K_EXTEND); launchExtend(lc, h->dsc, dc, pm, h->acc, wf, true); t.done(); }
+    scan((size_t)perStage, 1);
+    { Timed t(h, PT_K_OCCLUDED); launchShadeOccluded(lc, h->dsc, dc, pm, h->acc, wf); t.done(); }
   } else {
     stage(1, true);
     if (dc.mode == 1)      // depth 0..maxDepth can still spawn a ray (the check is depth > maxDepth, rendering.d:380)

@@ -211,6 +211,9 @@ __device__ __forceinline__ float4 loadLacc(const float4* Lacc, uint32_t slot, ui
 }
 // primary: the queue was filled by the shading of view-ray hits
 void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, bool primary);
+// shading of the view-ray hits + their sun and sky rays in one traversal launch (mode 0, sky, no light groups): reads
+// wf.hitQ, stores the radiance records
+void launchShadeOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc, const Wavefront& wf);
 // raygen + trace of the view rays + shading of their hits in one launch (wf.fuse != 0): fills the radiance records and
 // wf.rayOut = the hit queue of the chains' first rays
 void launchSampleTraced(const LaunchCfg& lc, const SceneBox& box, const ViewMasks& masks, const DevScene& sc, const DevCfg& cfg,

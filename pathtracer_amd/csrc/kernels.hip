@@ -1400,6 +1400,63 @@ __global__ void __launch_bounds__(PT_FUSE_THREADS, PT_FUSE_WAVES) k_sample_trace
   if (threadIdx.x == 0) wf.rayOut.count[T] = sCnt[0];
 }
 
+// View-ray hits of a scene whose vertices trace nothing but a sun and a sky ray (mode 0, sky, no light group), when
+// the scene is too large for the shading kernel to hold: the shading of the hit (the body of k_shade<PRIMARY>:
+// generator, normal, material, the two directions) moves into the traversal kernel that traces those rays, which
+// reads the hit queue instead of a queue of sun/sky entries.  No shade launch, no 64-byte entry written and read
+// back per vertex; L = 0 + sun + sky is stored once, with the tag.  Same operations per vertex as k_shade followed by
+// k_occluded (direct).
+template <bool LDSS>
+__global__ void PT_TRAVERSAL_BOUNDS k_shade_occluded(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, Wavefront wf) {
+  __shared__ __align__(16) WorkPool pool;
+  initPool(&pool);
+  stageScene<LDSS>(sc);
+  __syncthreads();
+  const ShadeTables<false> tb{sc, 0};
+  const QMeta q = wf.hitQ;
+  const uint32_t total = q.prefix[PT_SEGS], segCap = wf.capHit / PT_SEGS;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    statAdd(wf.stats, STAT_HITS, (unsigned long long)total); statAdd(wf.stats, STAT_HITS_PRIMARY, (unsigned long long)total);
+  }
+  uint32_t nRays = 0, nEnv = 0, cN = 0, cT = 0;
+  SegCursor cur; cur.seg = 0; cur.lo = 1; cur.hi = 0;
+  Chunk ck;
+  while (nextChunk(&pool, wf.taskCounters + 1, q, total, 0, ck)) {
+    uint32_t j = ck.begin + (threadIdx.x & 63u);
+    if (j < ck.end) {
+      uint32_t e = physIndexHint(q, j, ck.seg, segCap, cur);
+      float4 ha = wf.hitA[e], hb = wf.hitB[e];
+      const V3 hitPos = xyz(ha); const uint32_t laneSlot = f2u(hb.z);
+      uint32_t s = fdiv(pm.divNpix, laneSlot), lp = laneSlot - s * pm.npix;
+      uint32_t gp = mapPixel(pm, cfg.W, lp);
+      uint32_t sampleIdx = cfg.sampleBase + ((uint32_t)acc[gp].w + s) * cfg.sampleStride;
+      Rng g; g.seed(cfg.seed, gp, sampleIdx, 0);
+      g.next(); g.next();                                              // the x and y jitter of getViewRay
+      V3 normal, color; uint32_t matTag;
+      vertexTables(tb, f2u(ha.w), hb.x, hb.y, normal, color, matTag);
+      const V3 Tw = v3(1, 1, 1) * (PT_BRDF * color);
+      const EnvSample es = sampleEnv(cfg, g, normal);
+      float4 L = make_float4(0.0f, 0.0f, 0.0f, u2f(matTag));
+      if (es.eSun || es.eSky) {
+        const V3 org = hitPos + normal * 0.1f;
+        bool vSun = false, vSky = false;
+        Hit h;
+        if (es.eSun) vSun = !traverse<true, LDSS, false, true>(sc, org, es.dSun, cfg.eps, h, cN, cT);
+        if (es.eSky) vSky = !traverse<true, LDSS, false>(sc, org, es.dSky, cfg.eps, h, cN, cT);
+        nRays += (es.eSun ? 1u : 0u) + (es.eSky ? 1u : 0u); nEnv++;
+        if (vSun) { V3 c = Tw * cfg.sunRadiance * es.sSun; L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; }
+        if (vSky) { V3 c = Tw * cfg.skyRadiance * es.sSky; L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; }
+      }
+      wf.Lacc[laneSlot] = L;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) { nRays += __shfl_down(nRays, off); nEnv += __shfl_down(nEnv, off); }
+  if ((threadIdx.x & 63) == 0) {
+    if (nRays) statAdd(wf.stats, STAT_RAYS_OCCL, (unsigned long long)nRays);
+    if (nEnv) statAdd(wf.stats, STAT_ENV_ENTRIES, (unsigned long long)nEnv);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ accumulate
 // pixel.sum += L; pixel.n += 1 for each of the batch's k samples of a pixel, in sample order
 // (rendering.d:477-482; the (sum / N) of the indirect chains as in the block at rendering.d:474-477).
@@ -1670,6 +1727,16 @@ void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, con
   else if (primary) hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
   else if (lds) hipLaunchKernelGGL((k_shade<false, true>), grid, block, lds, lc.stream, sc, cfg, pm, acc, wf, numKinds);
   else hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+}
+
+void launchShadeOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc, const Wavefront& wf) {
+  Geo g = traversalGeo(lc, sc, wf.capQueue);
+  if (sc.ldsBytes) {
+    allowLds(lc, (const void*)k_shade_occluded<true>, g.lds);
+    hipLaunchKernelGGL(k_shade_occluded<true>, g.grid, g.block, g.lds, lc.stream, sc, cfg, pm, acc, wf);
+  } else {
+    hipLaunchKernelGGL(k_shade_occluded<false>, g.grid, g.block, 0, lc.stream, sc, cfg, pm, acc, wf);
+  }
 }
 
 void launchSampleTraced(const LaunchCfg& lc, const SceneBox& box, const ViewMasks& masks, const DevScene& sc, const DevCfg& cfg,

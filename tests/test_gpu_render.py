@@ -435,3 +435,25 @@ def test_shading_that_traces_its_own_rays_equals_the_queued_path(require_gpu, na
     assert sb.kernelLaunches[k.index('extend')] == (2 if mode == 0 else 2 * (2 + 4))
     assert sa.kernelLaunches[k.index('occluded')] == 0 and sa.kernelLaunches[k.index('connect')] == 0
     assert (sb.kernelLaunches[k.index('occluded')] > 0) == bool(sky) and (sb.kernelLaunches[k.index('connect')] > 0) == lights
+
+
+@pytest.mark.parametrize('flags', [0, P.PT_FLAG_NO_LDS_SCENE])
+def test_traversal_kernel_that_shades_its_hits_equals_the_queued_path(require_gpu, flags):
+    """Mode 0, sky, no light group, a scene too large for the shading kernel's LDS (the teapot): the kernel that traces
+    the sun and sky rays shades the view-ray hits itself, from the hit queue.  Same bits and counters as shade followed
+    by occluded (PT_FLAG_NO_FUSE), and no shade launch."""
+    W, H, spp = 160, 96, 6
+    out = []
+    for extra in (0, P.PT_FLAG_NO_FUSE):
+        pt = make_tracer('teapot', W, H, has_sky=1, mode=0, seed=3, flags=flags | extra | P.PT_FLAG_TIME_KERNELS)
+        pt.render_frame(spp); pt.render_frame(2)
+        out.append((pt.read_pixels(), pt.stats()))
+        pt.close()
+    (a, sa), (b, sb) = out
+    assert np.array_equal(a['n'], b['n']) and np.array_equal(a['sum'].view(np.uint32), b['sum'].view(np.uint32))
+    for f in ('raysPrimary', 'raysOcclusion', 'raysCulled', 'hits', 'hitsPrimary', 'envEntries', 'samples'):
+        assert getattr(sa, f) == getattr(sb, f), f
+    assert sa.raysOcclusion > 0 and sa.hits > 0
+    k = list(P.PT_K_NAMES)
+    assert sa.kernelLaunches[k.index('shade')] == 0 and sb.kernelLaunches[k.index('shade')] == 2
+    assert sa.kernelLaunches[k.index('occluded')] == 2 and sb.kernelLaunches[k.index('occluded')] == 2
