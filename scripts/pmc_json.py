@@ -33,6 +33,8 @@ def parse(path):
 def kind_of(name):
     if name.startswith('k_extend_refill<'):
         return 'extend'
+    if name.startswith('k_shade_occluded<'):
+        return 'occluded'                                   # the traversal kernel that shades the hits it reads
     if name.startswith('k_shade_traced<') or name.startswith('k_sample_traced'):
         return 'shade'                                      # shading that traces its own rays; the whole-sample kernel
     for k in ('extend', 'connect', 'occluded', 'shade', 'accumulate', 'raygen'):
