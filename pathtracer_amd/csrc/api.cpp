@@ -511,6 +511,26 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
     HIPCHECK(hipGetLastError());
     return;
   }
+  // the view rays generated and traced by one traversal launch (not with the visit counters, which count in extend)
+  // (scenes in global memory keep the queue: their extend hands freed lanes the next ray, which needs one)
+  const bool rayExt = !wf.fuse && h->dsc.ldsBytes && !lc.countVisits && !(h->cfg.flags & PT_FLAG_NO_FUSE);
+  if (rayExt) {
+    bind(1);
+    { Timed t(h, PT_K_EXTEND); launchRaygenExtend(lc, h->box, ws.masks, h->dsc, dc, pm, h->acc, nslots, wf); t.done(); }
+    scan((size_t)perStage, 1);
+    if (dc.mode == 0 && envDirect(dc, h->dsc, true)) {
+      { Timed t(h, PT_K_OCCLUDED); launchShadeOccluded(lc, h->dsc, dc, pm, h->acc, wf); t.done(); }
+    } else {
+      { Timed t(h, PT_K_SHADE); launchShade(lc, h->dsc, dc, pm, h->acc, wf, true); t.done(); }
+      scan((size_t)perStage + 1, 1 + kinds);
+      launchShadowKinds(h, lc, dc, wf, true);
+      if (dc.mode == 1)
+        for (uint32_t round = 0; round <= dc.maxDepth; round++) stage(round + 2, false);
+    }
+    { Timed t(h, PT_K_ACCUM); launchAccumulate(lc, ws.masks, dc, pm, h->acc, wf, h->dsc); t.done(); }
+    HIPCHECK(hipGetLastError());
+    return;
+  }
   wf.rayOut = ws.hostMetas[1];
   { Timed t(h, PT_K_OTHER); launchRaygen(lc, h->box, ws.masks, dc, pm, h->acc, nslots, wf); t.done(); }
   scan(1, 1);

@@ -211,6 +211,10 @@ __device__ __forceinline__ float4 loadLacc(const float4* Lacc, uint32_t slot, ui
 }
 // primary: the queue was filled by the shading of view-ray hits
 void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, bool primary);
+// raygen + extend of the view rays in one traversal launch: fills wf.hitQ (counts) and the radiance records of the
+// misses.  wf.taskCounters[PT_TASK_COUNTERS - 1] must be zero (it is after any launchScan).
+void launchRaygenExtend(const LaunchCfg& lc, const SceneBox& box, const ViewMasks& masks, const DevScene& sc, const DevCfg& cfg,
+                        const PixMap& pm, const float4* acc, uint32_t nslots, const Wavefront& wf);
 // shading of the view-ray hits + their sun and sky rays in one traversal launch (mode 0, sky, no light groups): reads
 // wf.hitQ, stores the radiance records
 void launchShadeOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc, const Wavefront& wf);

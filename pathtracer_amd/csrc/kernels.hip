@@ -812,6 +812,96 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend_refill(DevScene sc, DevCfg cfg, Pix
 // 28.2 -> 28.3 ms per 4 spp.  Their rays start at scattered hit points, half of their node and triangle fetches miss
 // the L2, and the launches move 0.6-0.7 of the HBM peak: memory, not idle lanes, is what they wait for.)
 
+// Raygen and the extend of the view rays in one traversal launch: a wave takes runs of 64 path slots (a pixel tile at
+// one sample number), decides each slot as k_raygen does (constant sky: nothing; not covered: sampleSky; covered: the
+// view ray) and traces the covered ones right away -- no view-ray queue (16 B written and read per traced ray), no
+// raygen launch, no scan.  Runs whose pixels are all culled cost a mask word per lane.  Slots are handed out like queue
+// entries (a global counter gives a workgroup PT_RUN_PIECE slots at a time, its waves take 64 at a time), hits are
+// appended like extend's.  The counter must be zero at launch: the scan of the hit queue, which follows this kernel
+// in every batch, clears it for the next batch.
+constexpr uint32_t PT_RUN_PIECE = PT_SUPER;      // PT_HIT_SLACK is sized for pieces of PT_SUPER (kernels.h)
+__device__ __forceinline__ bool nextSlots(WorkPool* p, uint32_t* counter, uint32_t total, uint32_t outLimit, uint32_t& begin) {
+  uint32_t b = 0xFFFFFFFFu;
+  if ((threadIdx.x & 63) == 0) {
+    volatile WorkPool* vp = p;
+    for (;;) {
+      unsigned long long st = vp->state;
+      uint32_t next = (uint32_t)st, end = (uint32_t)(st >> 32);
+      if (next < end) {
+        if (atomicCAS(&p->state, st, st + 64) == st) { b = next; break; }
+        continue;
+      }
+      if (vp->done) break;
+      if (atomicCAS(&p->lock, 0u, 1u) == 0u) {
+        st = vp->state;
+        if ((uint32_t)st >= (uint32_t)(st >> 32) && !vp->done) {
+          // every slot can become a hit: the workgroup stops taking slots when a piece more could overflow its region
+          bool full = vp->out + blockDim.x + PT_RUN_PIECE > outLimit;
+          uint32_t g = full ? 0xFFFFFFFFu : atomicAdd(counter, PT_RUN_PIECE);
+          if (g >= total) vp->done = 1;
+          else { __threadfence_block(); atomicExch(&p->state, ((unsigned long long)min(g + PT_RUN_PIECE, total) << 32) | g); }
+        }
+        __threadfence_block();
+        atomicExch(&p->lock, 0u);
+      } else {
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+  }
+  begin = __builtin_amdgcn_readfirstlane(b);
+  return begin != 0xFFFFFFFFu;
+}
+
+template <bool LDSS>
+__global__ void PT_TRAVERSAL_BOUNDS k_raygen_extend(SceneBox box, ViewMasks masks, DevScene sc, DevCfg cfg, PixMap pm,
+                                                    const float4* __restrict__ acc, uint32_t nslots, Wavefront wf) {
+  __shared__ __align__(16) WorkPool pool;
+  initPool(&pool);
+  stageScene<LDSS>(sc);
+  __syncthreads();
+  const uint32_t segCapOut = wf.capHit / PT_SEGS;
+  const uint32_t segFirst = (uint32_t)(((uint64_t)blockIdx.x * PT_SEGS) / gridDim.x);
+  const uint32_t segLast = (uint32_t)(((uint64_t)(blockIdx.x + 1) * PT_SEGS) / gridDim.x);
+  const uint32_t outBase = segFirst * segCapOut, outLimit = (segLast - segFirst) * segCapOut;
+  uint32_t culled = 0, cN = 0, cT = 0, begin;
+  while (nextSlots(&pool, wf.taskCounters + (PT_TASK_COUNTERS - 1), nslots, outLimit, begin)) {
+    const uint32_t i = begin + (threadIdx.x & 63u);
+    const bool valid = i < nslots;
+    uint32_t s, gp = slotPixel(cfg, pm, valid ? i : 0u, s);
+    const bool constant = valid && masks.constantSky && maskBit(masks.constantSky, gp);
+    const bool live = valid && !constant;
+    if (constant) culled++;
+    bool isHit = false; V3 d = v3(0, 0, 0); Hit h; h.t = 0; h.u = 0; h.v = 0; h.tri = 0;
+    if (live) {
+      d = primaryRayFrom(cfg, gp, s, acc[gp].w, true).d;
+      bool enter;
+      if (masks.covered) enter = maskBit(masks.covered, gp);
+      else {
+        RayInv ri = makeRayInv(cfg.cam.pos, d);
+        float tn;
+        enter = slab(ri, box.mn[0], box.mn[1], box.mn[2], box.mx[0], box.mx[1], box.mx[2], PT_FLT_MAX, tn);
+      }
+      if (enter) isHit = traverse<false, LDSS, false>(sc, cfg.cam.pos, d, cfg.eps, h, cN, cT);
+      else culled++;
+      if (!isHit) wf.Lacc[i] = f4(sampleSky(d), 0.0f);                                   // rendering.d:480
+    }
+    uint32_t idx = waveAppend(isHit, &pool.out);
+    if (isHit) {
+      uint32_t e = outBase + idx;
+      wf.hitA[e] = f4(cfg.cam.pos + d * h.t, u2f(h.tri));
+      wf.hitB[e] = make_float4(h.u, h.v, u2f(i), h.t);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) culled += __shfl_down(culled, off);
+  if ((threadIdx.x & 63) == 0 && culled) statAdd(wf.stats, STAT_RAYS_CULLED, (unsigned long long)culled);
+  __syncthreads();
+  uint32_t n = pool.out;
+  for (uint32_t sg = segFirst + threadIdx.x; sg < segLast; sg += blockDim.x) {
+    uint32_t before = (sg - segFirst) * segCapOut;
+    wf.hitQ.count[sg] = n > before ? min(n - before, segCapOut) : 0u;
+  }
+}
+
 // View rays generated in registers, no cull, no queue: the parity probe (getViewRay without jitter + Scene.trace).
 template <bool LDSS, bool COUNT>
 __global__ void PT_TRAVERSAL_BOUNDS k_extend_primary(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc,
@@ -1727,6 +1817,18 @@ void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, con
   else if (primary) hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
   else if (lds) hipLaunchKernelGGL((k_shade<false, true>), grid, block, lds, lc.stream, sc, cfg, pm, acc, wf, numKinds);
   else hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, lc.stream, sc, cfg, pm, acc, wf, numKinds);
+}
+
+void launchRaygenExtend(const LaunchCfg& lc, const SceneBox& box, const ViewMasks& masks, const DevScene& sc, const DevCfg& cfg,
+                        const PixMap& pm, const float4* acc, uint32_t nslots, const Wavefront& wf) {
+  Geo g = traversalGeo(lc, sc, wf.capQueue);
+  g.grid.x = std::min<unsigned>(g.grid.x, PT_SEGS);      // every workgroup owns at least one output segment
+  if (sc.ldsBytes) {
+    allowLds(lc, (const void*)k_raygen_extend<true>, g.lds);
+    hipLaunchKernelGGL(k_raygen_extend<true>, g.grid, g.block, g.lds, lc.stream, box, masks, sc, cfg, pm, acc, nslots, wf);
+  } else {
+    hipLaunchKernelGGL(k_raygen_extend<false>, g.grid, g.block, 0, lc.stream, box, masks, sc, cfg, pm, acc, nslots, wf);
+  }
 }
 
 void launchShadeOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc, const Wavefront& wf) {

@@ -31,7 +31,7 @@ def parse(path):
 
 
 def kind_of(name):
-    if name.startswith('k_extend_refill<'):
+    if name.startswith('k_extend_refill<') or name.startswith('k_raygen_extend<'):
         return 'extend'
     if name.startswith('k_shade_occluded<'):
         return 'occluded'                                   # the traversal kernel that shades the hits it reads
