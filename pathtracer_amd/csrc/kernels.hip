@@ -163,7 +163,10 @@ struct Hit { float t, u, v; uint32_t tri; bool front; };
 #endif
 // Diagnostic builds (scripts/build_variant.sh <tag> -D...; never defined in the library that ships):
 //   PT_STAMP / PT_SLOTS   the counting variants report wave clock ticks / lane slots of the descent loop instead of visits
-//   PT_PROBE_HALF=n       extend gives a wave n rays instead of 64 (what part of a launch depends on busy lanes)
+//   PT_PROBE_HALF=n       extend gives a wave n rays instead of 64 (what part of a launch depends on busy lanes);
+//   PT_PROBE_OCC=n        the same for the sun/sky kernel
+//   PT_PROBE_TRI2         every triangle test of a scene in global memory fetches a second, random triangle as well
+//                         (what triangle traffic costs: +18-20 % on the 10 M-triangle soup's traversal kernels)
 //   PT_PROBE_A / _B / _C  the traced shading without its chain traversals / its chain loop / its sun and sky traversals
 //                         (wrong images: timing only)
 #if defined(PT_STAMP) || defined(PT_SLOTS)
@@ -188,6 +191,13 @@ template <bool ANY, bool LDSS, bool BOTH = false>
 __device__ __forceinline__ bool testTriangle(const DevScene& sc, uint32_t row, V3 o, V3 d, float eps, Hit& h, bool& found) {
   float4 t0 = ldTri<LDSS>(sc, row), tA = ldTri<LDSS>(sc, row + 1), tB = ldTri<LDSS>(sc, row + 2);
   keepW<LDSS>(tA, tB); keepW<LDSS>(t0, t0);
+#ifdef PT_PROBE_TRI2
+  if constexpr (!LDSS) {       // as many bytes again from a random other triangle: what triangle traffic costs
+    uint32_t r2 = ((row / 3) * 2654435761u) % sc.numTris * 3;
+    float4 x0 = sc.tris[r2], x1 = sc.tris[r2 + 1], x2 = sc.tris[r2 + 2];
+    asm volatile("" ::"v"(x0.x), "v"(x1.x), "v"(x2.x));
+  }
+#endif
   V3 A = xyz(tA), B = xyz(tB);
   V3 p = cross(d, B);
   float det = dot(A, p);
@@ -1021,7 +1031,11 @@ __global__ void PT_TRAVERSAL_BOUNDS k_occluded(DevScene sc, float eps, V3 sunRad
   Chunk ck;
   while (nextChunk(&pool, taskCounter, q, total, 0, ck)) {
     uint32_t j = ck.begin + (threadIdx.x & 63u);
+#ifdef PT_PROBE_OCC
+    if (j < ck.end && (threadIdx.x & 63u) < PT_PROBE_OCC) {
+#else
     if (j < ck.end) {
+#endif
       uint32_t e = physIndexHint(q, j, ck.seg, segCap, cur);
       float4 ro = shO[e], a = shD[e], b = shW[e];
       bool eSun = a.x != 0.0f || a.y != 0.0f || a.z != 0.0f, eSky = b.x != 0.0f || b.y != 0.0f || b.z != 0.0f;
