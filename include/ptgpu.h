@@ -72,10 +72,14 @@ typedef struct PtConfig {
 #define PT_FLAG_NO_GRAPH 64u      /* never replay a small batch from a HIP graph (default: a ptgpu_render / _bands call that is
                                      one batch of at most 4 Mi samples is captured the second time it is issued with the
                                      same arguments, scene, camera and configuration, and replayed from then on)     */
-#define PT_FLAG_NO_FUSE 128u      /* never trace rays inside the shading kernel (default: when nodes, triangles and shading
-                                     tables together fit in 24 KB of LDS, shading traces the rays it spawns itself --
-                                     light-sample rays, sun / sky rays, continuation rays of the indirect chains --
-                                     instead of queueing them; same rays, same results)                            */
+#define PT_FLAG_NO_FUSE 128u      /* one launch per stage of the wavefront (raygen, extend, shade, connect, occluded), queues
+                                     in between.  Default: stages are merged where that saves queue traffic and
+                                     launches with the same rays and results -- scenes whose nodes, triangles and
+                                     shading tables fit in 24 KB of LDS: shading traces the rays it spawns (light-sample
+                                     rays, sun / sky rays, continuation rays of the chains), and raygen + view ray + its
+                                     shading are one kernel; larger scenes in LDS: the view rays are generated by the
+                                     kernel that traces them; mode 0 with sky and no light group: the kernel that traces
+                                     the sun / sky rays shades the view-ray hits itself                             */
 #define PT_FLAG_QUEUED_VIEW_RAYS 256u /* with traced shading: keep raygen, extend and shade as separate launches for the
                                      view rays (default: one kernel generates a sample's view ray, traces it and shades
                                      its hit)                                                                        */
