@@ -1432,7 +1432,16 @@ __global__ void __launch_bounds__(PT_FUSE_THREADS, PT_FUSE_WAVES) k_shade_traced
 // Scene.trace of the view ray and the shading of its hit, slot by slot -- no view-ray queue, no hit queue for view
 // rays, no generator re-seeded in shade (the lane still holds the sample's stream past its two jitter draws).  What
 // leaves the kernel is the sample's radiance record and the hits of the chains' first rays.
-__global__ void __launch_bounds__(PT_FUSE_THREADS, PT_FUSE_WAVES) k_sample_traced(SceneBox box, ViewMasks masks, DevScene sc, DevCfg cfg, PixMap pm,
+// Its launch fills the chip in one round: PT_SAMPLE_GROUPS workgroups of PT_SAMPLE_THREADS threads are two workgroups
+// of 12 waves per CU, six waves per SIMD (1024 workgroups of 8 waves needed a second round a third full).
+#ifndef PT_SAMPLE_THREADS
+#define PT_SAMPLE_THREADS 768
+#endif
+#ifndef PT_SAMPLE_GROUPS
+#define PT_SAMPLE_GROUPS 512
+#endif
+static_assert(PT_SEGS % PT_SAMPLE_GROUPS == 0, "a workgroup appends to a whole number of segments");
+__global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_FUSE_WAVES) k_sample_traced(SceneBox box, ViewMasks masks, DevScene sc, DevCfg cfg, PixMap pm,
                                                                    const float4* __restrict__ acc, uint32_t nslots, Wavefront wf) {
   __shared__ uint32_t sCnt[1 + PT_MAX_KINDS];
   if (threadIdx.x <= PT_MAX_KINDS) sCnt[threadIdx.x] = 0;
@@ -1440,11 +1449,13 @@ __global__ void __launch_bounds__(PT_FUSE_THREADS, PT_FUSE_WAVES) k_sample_trace
   const ShadeTables<true> tb{sc, 2 * sc.numNodes + 3 * sc.numTris};
   tb.stage();
   __syncthreads();
-  // Runs of 64 slots (one wave: a tile of pixels at one sample number) are dealt out to the block-tasks in turn, run c
-  // to task c % PT_SEGS, and a task's runs to its waves as they become free: the work of a run ranges from nothing (sky) to a
-  // vertex with all its rays, and contiguous shares would leave the tasks that cover background idle.  A task gets at
-  // most capSlots / (64 * PT_SEGS) runs, so what it appends fits its segment.  Waves do not wait for each other.
-  const uint32_t T = blockIdx.x, runs = (nslots + 63u) >> 6;
+  // Runs of 64 slots (one wave: a tile of pixels at one sample number) are dealt out to the workgroups in turn, run c
+  // to workgroup c % gridDim.x, and a workgroup's runs to its waves as they become free: the work of a run ranges from
+  // nothing (sky) to a vertex with all its rays, and contiguous shares would leave the workgroups that cover background
+  // idle.  A workgroup appends to its PT_SEGS / gridDim.x adjacent segments as one region; it gets at most
+  // capSlots / (64 * gridDim.x) runs, so what it appends fits.  Waves do not wait for each other.
+  const uint32_t G = gridDim.x, segsPer = PT_SEGS / G, runs = (nslots + 63u) >> 6;
+  const uint32_t T = blockIdx.x * segsPer;                 // first segment of this workgroup's region
   const uint32_t segCap = wf.capQueue / PT_SEGS;
   ShadeCtx cx{sc, cfg, wf, sCnt, T, segCap, segCap};
   cx.segCapHit = wf.capHit / PT_SEGS;
@@ -1456,7 +1467,7 @@ __global__ void __launch_bounds__(PT_FUSE_THREADS, PT_FUSE_WAVES) k_sample_trace
   for (;;) {
     uint32_t k = 0;
     if ((threadIdx.x & 63u) == 0) k = atomicAdd(&sNextRun, 1u);
-    const uint32_t run = T + PT_SEGS * (uint32_t)__builtin_amdgcn_readfirstlane(k);
+    const uint32_t run = blockIdx.x + G * (uint32_t)__builtin_amdgcn_readfirstlane(k);
     if (run >= runs) break;
     const uint32_t i = (run << 6) + (threadIdx.x & 63u);
     const bool valid = i < nslots;
@@ -1501,7 +1512,10 @@ __global__ void __launch_bounds__(PT_FUSE_THREADS, PT_FUSE_WAVES) k_sample_trace
     if (mine > culled) statAdd(wf.stats, STAT_FUSED_PRIMARY, (unsigned long long)(mine - culled));     // view rays traced here
   }
   __syncthreads();
-  if (threadIdx.x == 0) wf.rayOut.count[T] = sCnt[0];
+  if (threadIdx.x < segsPer) {
+    const uint32_t n = sCnt[0], before = threadIdx.x * cx.segCapHit;
+    wf.rayOut.count[T + threadIdx.x] = n > before ? min(n - before, cx.segCapHit) : 0u;
+  }
 }
 
 // View-ray hits of a scene whose vertices trace nothing but a sun and a sky ray (mode 0, sky, no light group), when
@@ -1858,7 +1872,7 @@ void launchShadeOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& 
 void launchSampleTraced(const LaunchCfg& lc, const SceneBox& box, const ViewMasks& masks, const DevScene& sc, const DevCfg& cfg,
                         const PixMap& pm, const float4* acc, uint32_t nslots, const Wavefront& wf) {
   const uint32_t all = shadeTableBytes(sc) + (uint32_t)sc.ldsBytes;
-  hipLaunchKernelGGL(k_sample_traced, dim3(PT_SEGS), dim3(PT_FUSE_THREADS), all, lc.stream, box, masks, sc, cfg, pm, acc, nslots, wf);
+  hipLaunchKernelGGL(k_sample_traced, dim3(PT_SAMPLE_GROUPS), dim3(PT_SAMPLE_THREADS), all, lc.stream, box, masks, sc, cfg, pm, acc, nslots, wf);
 }
 
 void launchAccumulate(const LaunchCfg& lc, const ViewMasks& masks, const DevCfg& cfg, const PixMap& pm, float4* acc,
