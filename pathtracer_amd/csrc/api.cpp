@@ -393,7 +393,7 @@ void ensureWavefront(PtHandle* h) {
   // queue bookkeeping: stage s owns 2 + PT_MAX_KINDS queues: [0] the hit queue its extend fills, [1] the ray queue
   // and [2 + kind] the shadow queues its shade fills
   const uint32_t perStage = 2 + PT_MAX_KINDS;
-  h->bCounters.alloc((size_t)rounds * perStage * PT_QMETA_WORDS * 4 + PT_TASK_COUNTERS * 4);
+  h->bCounters.alloc((size_t)rounds * perStage * PT_QMETA_WORDS * 4 + (PT_TASK_COUNTERS + PT_POOL_WORDS) * 4);
   h->bMetaDesc.alloc((size_t)rounds * perStage * sizeof(QMeta));
   h->metas.resize((size_t)rounds * perStage);
   uint32_t* words = h->bCounters.as<uint32_t>();
@@ -404,6 +404,7 @@ void ensureWavefront(PtHandle* h) {
   HIPCHECK(hipMemset(h->bCounters.p, 0, h->bCounters.bytes));
   HIPCHECK(hipMemcpy(h->bMetaDesc.p, h->metas.data(), h->metas.size() * sizeof(QMeta), hipMemcpyHostToDevice));
   w.taskCounters = words + h->metas.size() * PT_QMETA_WORDS;
+  w.runPool = (h->cfg.flags & PT_FLAG_STATIC_RUNS) ? nullptr : w.taskCounters + PT_TASK_COUNTERS;
   w.slotQ = h->bSlotQ.as<float4>(); w.hitA = h->bHitA.as<float4>(); w.hitB = h->bHitB.as<float4>();
   w.rayO = h->bRayO.as<float4>(); w.rayD = h->bRayD.as<float4>();
   w.Lacc = h->bLacc.as<float4>(); w.thr = h->bThr.as<float4>(); w.rng = h->bRng.as<uint2>();
@@ -876,7 +877,7 @@ NoAllocLayout layoutNoAlloc(const PtHandle* h, uint32_t capSlots) {
   L.shO = piece((uint64_t)L.kinds * capQueue * 16); L.shD = piece((uint64_t)L.kinds * capQueue * 16);
   L.shW = piece((uint64_t)L.kinds * capQueue * 16); L.shX = piece(capQueue * 16);
   const uint64_t nMetas = (uint64_t)L.rounds * (2 + PT_MAX_KINDS);
-  L.words = piece(nMetas * PT_QMETA_WORDS * 4 + PT_TASK_COUNTERS * 4);
+  L.words = piece(nMetas * PT_QMETA_WORDS * 4 + (PT_TASK_COUNTERS + PT_POOL_WORDS) * 4);
   L.desc = piece(nMetas * sizeof(QMeta));
   L.total = at;
   return L;
@@ -918,12 +919,13 @@ int ptgpu_render_noalloc(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount,
       h->metasNoAlloc[m] = QMeta{p, p + PT_SEGS, p + 2 * PT_SEGS + 2};
     }
     w.taskCounters = words + nMetas * PT_QMETA_WORDS;
+    w.runPool = (h->cfg.flags & PT_FLAG_STATIC_RUNS) ? nullptr : w.taskCounters + PT_TASK_COUNTERS;
     ws.hostMetas = h->metasNoAlloc.data(); ws.devMetas = (const QMeta*)(base + L.desc);
     // masks built for the current scene and camera are used; none is built here (that would allocate): the view rays
     // are then culled by the scene's bounding box, which gives the same image
     ws.masks = (!h->maskDirty && h->maskUsable) ? h->masks() : ViewMasks{nullptr, nullptr};
     // the array keeps the last call's contents (of this or any other handle on the device): counters start at zero
-    HIPCHECK(hipMemsetAsync(words, 0, nMetas * PT_QMETA_WORDS * 4 + PT_TASK_COUNTERS * 4, h->stream));
+    HIPCHECK(hipMemsetAsync(words, 0, nMetas * PT_QMETA_WORDS * 4 + (PT_TASK_COUNTERS + PT_POOL_WORDS) * 4, h->stream));
     // ... and so do the chain lanes' radiance records: whatever another call's layout left there must not be taken
     // for a record of this batch
     if (L.lanes > 1)

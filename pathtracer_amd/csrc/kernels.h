@@ -107,6 +107,9 @@ struct QMeta {
 };
 constexpr uint32_t PT_QMETA_WORDS = 3 * PT_SEGS + 2;
 constexpr int PT_TASK_COUNTERS = 16;   // one dynamic work counter per traversal launch of a stage
+// Counters of the runs that the whole-sample kernel's workgroups take from a common pool (k_sample_traced), each on a
+// cache line of its own; they follow the task counters and are zero between batches (k_accumulate clears them).
+constexpr int PT_POOL_COUNTERS = 8, PT_POOL_STRIDE = 64, PT_POOL_WORDS = PT_POOL_COUNTERS * PT_POOL_STRIDE;
 
 // Traversal kernels consume a queue dynamically: a workgroup takes PT_SUPER consecutive flat entries from the
 // launch's global counter into an LDS pool, and its waves take 64 at a time from the pool, independently of
@@ -140,6 +143,7 @@ struct Wavefront {
   QMeta rayOut;               // ray queue this stage's shade fills
   QMeta sh[PT_MAX_KINDS];     // shadow queues this stage's shade fills
   uint32_t* taskCounters;     // [PT_TASK_COUNTERS], zeroed by the scan that precedes the launches using them
+  uint32_t* runPool;          // [PT_POOL_WORDS] or null (every workgroup keeps to its own share of the runs)
   unsigned long long* stats;  // see STAT_*
   uint32_t capSlots;          // primary slots per batch (multiple of 64 * PT_SEGS)
   uint32_t capQueue;          // entries per ray / shadow queue (capSlots * max(1, numIndirect) in mode 1)

@@ -1440,8 +1440,17 @@ __global__ void __launch_bounds__(PT_FUSE_THREADS, PT_FUSE_WAVES) k_shade_traced
 #ifndef PT_SAMPLE_GROUPS
 #define PT_SAMPLE_GROUPS 512
 #endif
+#ifndef PT_POOL_CHUNK
+#define PT_POOL_CHUNK 4          // runs a wave takes from the pool at a time
+#endif
+#ifndef PT_POOL_PART
+#define PT_POOL_PART 4           // one run in PT_POOL_PART is in the common pool
+#endif
+#ifndef PT_SAMPLE_WAVES
+#define PT_SAMPLE_WAVES PT_FUSE_WAVES
+#endif
 static_assert(PT_SEGS % PT_SAMPLE_GROUPS == 0, "a workgroup appends to a whole number of segments");
-__global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_FUSE_WAVES) k_sample_traced(SceneBox box, ViewMasks masks, DevScene sc, DevCfg cfg, PixMap pm,
+__global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_SAMPLE_WAVES) k_sample_traced(SceneBox box, ViewMasks masks, DevScene sc, DevCfg cfg, PixMap pm,
                                                                    const float4* __restrict__ acc, uint32_t nslots, Wavefront wf) {
   __shared__ uint32_t sCnt[1 + PT_MAX_KINDS];
   if (threadIdx.x <= PT_MAX_KINDS) sCnt[threadIdx.x] = 0;
@@ -1460,15 +1469,51 @@ __global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_FUSE_WAVES) k_sample_tra
   ShadeCtx cx{sc, cfg, wf, sCnt, T, segCap, segCap};
   cx.segCapHit = wf.capHit / PT_SEGS;
   uint32_t culled = 0, hits = 0, mine = 0;
-  // a task's runs go to whichever of its waves is free next
-  __shared__ uint32_t sNextRun;
-  if (threadIdx.x == 0) sNextRun = 0;
+  // A workgroup's own runs go to whichever of its waves is free next.  The last quarter of the runs is a pool that all
+  // workgroups take from when their own are done (wf.runPool; PT_POOL_COUNTERS counters that deal out every
+  // PT_POOL_COUNTERS-th run of the pool each, a workgroup moves on to the next counter when one is used up): the
+  // workgroups' own shares differ by several per cent in the vertices they hold, and a launch ends with its slowest
+  // workgroup.  A pooled run is taken only while the region has room for it and for every run the workgroup's waves
+  // are working on, each counted with all the hits it can append (perRun).  The region holds more than a full share
+  // of such runs, so a workgroup declines only after it has done a share, and some workgroup can always take what is
+  // left.
+  __shared__ uint32_t sNextRun, sBusy, sUsedUp;
+  if (threadIdx.x == 0) { sNextRun = 0; sBusy = 0; sUsedUp = 0; }
   __syncthreads();
+  const uint32_t perRun = (cfg.mode == 1 ? cfg.numIndirect : 0u) * 64u, cap = segsPer * cx.segCapHit, share = (runs + G - 1) / G;
+  const bool pooled = wf.runPool && (perRun == 0 || cap / perRun >= share + PT_POOL_CHUNK);
+  const uint32_t own = pooled ? share - share / PT_POOL_PART : share, firstPooled = G * own;
+  uint32_t pending = 0, pendingRun = 0;                       // the rest of the piece this wave took from the pool
   for (;;) {
-    uint32_t k = 0;
-    if ((threadIdx.x & 63u) == 0) k = atomicAdd(&sNextRun, 1u);
-    const uint32_t run = blockIdx.x + G * (uint32_t)__builtin_amdgcn_readfirstlane(k);
-    if (run >= runs) break;
+    uint32_t run = PT_NONE;
+    if (pending) { run = pendingRun; pendingRun += PT_POOL_COUNTERS; pending--; }
+    else {
+      uint32_t got = 0;
+      if ((threadIdx.x & 63u) == 0) {
+        const uint32_t k = atomicAdd(&sNextRun, 1u);
+        if (k < own) {
+          run = blockIdx.x + G * k;
+          if (run < runs) { got = 1; atomicAdd(&sBusy, 1u); }
+        } else if (pooled) {
+          const uint32_t busy = atomicAdd(&sBusy, (uint32_t)PT_POOL_CHUNK) + PT_POOL_CHUNK;
+          if (atomicAdd(&sCnt[0], 0u) + busy * perRun <= cap) {
+            for (;;) {
+              const uint32_t usedUp = atomicAdd(&sUsedUp, 0u);
+              if (usedUp >= PT_POOL_COUNTERS) break;
+              const uint32_t c = (blockIdx.x + usedUp) % PT_POOL_COUNTERS;
+              const uint32_t r = firstPooled + c + PT_POOL_COUNTERS * atomicAdd(&wf.runPool[c * PT_POOL_STRIDE], (uint32_t)PT_POOL_CHUNK);
+              if (r < runs) { run = r; got = min((uint32_t)PT_POOL_CHUNK, (runs - r + PT_POOL_COUNTERS - 1) / PT_POOL_COUNTERS); break; }
+              atomicMax(&sUsedUp, usedUp + 1u);
+            }
+          }
+          atomicSub(&sBusy, PT_POOL_CHUNK - got);
+        }
+      }
+      got = (uint32_t)__builtin_amdgcn_readfirstlane(got);
+      if (!got) break;
+      run = (uint32_t)__builtin_amdgcn_readfirstlane(run);
+      pending = got - 1; pendingRun = run + PT_POOL_COUNTERS;
+    }
     const uint32_t i = (run << 6) + (threadIdx.x & 63u);
     const bool valid = i < nslots;
     if (valid) mine++;
@@ -1501,6 +1546,7 @@ __global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_FUSE_WAVES) k_sample_tra
       }
     }
     shadeVertex<true, true, true>(cx, tb, active, hitPos, normal, color, matTag, v3(1, 1, 1), 0u, g, gp, sampleIdx, i);
+    if ((threadIdx.x & 63u) == 0) atomicSub(&sBusy, 1u);              // after the run's appends
   }
   flushTraced(cx);
   for (int off = 32; off > 0; off >>= 1) { culled += __shfl_down(culled, off); hits += __shfl_down(hits, off); mine += __shfl_down(mine, off); }
@@ -1584,6 +1630,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_shade_occluded(DevScene sc, DevCfg cfg, Pi
 __global__ void __launch_bounds__(256) k_accumulate(ViewMasks masks, DevCfg cfg, PixMap pm, float4* __restrict__ acc, Wavefront wf,
                                                     const float4* __restrict__ mats) {
   uint32_t lp = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < PT_POOL_COUNTERS && wf.runPool) wf.runPool[threadIdx.x * PT_POOL_STRIDE] = 0;   // the batch is over
   if (lp >= pm.npix) return;
   uint32_t gp = mapPixel(pm, cfg.W, lp);
   float4 a = acc[gp];

@@ -437,6 +437,27 @@ def test_shading_that_traces_its_own_rays_equals_the_queued_path(require_gpu, na
     assert (sb.kernelLaunches[k.index('occluded')] > 0) == bool(sky) and (sb.kernelLaunches[k.index('connect')] > 0) == lights
 
 
+@pytest.mark.parametrize('name,sky,mode', [('chest1', 1, 1), ('cornell-box', 1, 1), ('cornell-box', 0, 0)])
+def test_samples_taken_from_the_common_pool_equal_the_workgroups_own_shares(require_gpu, name, sky, mode):
+    """The one-kernel-per-sample path on a frame large enough for the pool (a quarter of the 64-sample runs, taken by
+    whichever workgroup is free): same bits and counters as with every workgroup keeping to its own share
+    (PT_FLAG_STATIC_RUNS) and as the queued path, over two batches (the pool's counters are cleared in between)."""
+    W, H, spp = 512, 384, 10
+    out = []
+    for flags in (0, P.PT_FLAG_STATIC_RUNS, P.PT_FLAG_NO_FUSE):
+        pt = make_tracer(name, W, H, has_sky=sky, mode=mode, seed=5, max_depth=3, flags=flags)
+        pt.render_frame(spp)
+        pt.render_frame(7)
+        out.append((pt.read_pixels(), pt.stats()))
+        pt.close()
+    (a, sa) = out[0]
+    assert sa.raysPrimaryInShade > 0
+    for x, sx in out[1:]:
+        assert np.array_equal(a['n'], x['n']) and np.array_equal(a['sum'].view(np.uint32), x['sum'].view(np.uint32))
+        for f in ('raysPrimary', 'raysLight', 'raysIndirect', 'raysOcclusion', 'raysCulled', 'hits', 'hitsPrimary', 'envEntries', 'samples'):
+            assert getattr(sa, f) == getattr(sx, f), f
+
+
 @pytest.mark.parametrize('flags', [0, P.PT_FLAG_NO_LDS_SCENE])
 def test_traversal_kernel_that_shades_its_hits_equals_the_queued_path(require_gpu, flags):
     """Mode 0, sky, no light group, a scene too large for the shading kernel's LDS (the teapot): the kernel that traces
