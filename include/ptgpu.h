@@ -84,7 +84,8 @@ typedef struct PtConfig {
                                      view rays (default: one kernel generates a sample's view ray, traces it and shades
                                      its hit)                                                                        */
 #define PT_FLAG_STATIC_RUNS 512u  /* the one-kernel-per-sample path: every workgroup keeps to its own share of the samples
-                                     (default: the last quarter is a pool that workgroups take from as they finish) */
+                                     (default: the 64-sample runs of a large launch, and the last quarter of those
+                                     of a small one, are a pool that workgroups take from as they finish)        */
 #define PT_FLAG_NO_TREELETS 1024u   /* scenes traversed from global memory: keep the builder's order of the node pairs
                                      (default: pairs are laid out so that a 128-byte line holds a pair with
                                      descendants of it)                                                              */

@@ -1443,8 +1443,8 @@ __global__ void __launch_bounds__(PT_FUSE_THREADS, PT_FUSE_WAVES) k_shade_traced
 #ifndef PT_POOL_CHUNK
 #define PT_POOL_CHUNK 4          // runs a wave takes from the pool at a time
 #endif
-#ifndef PT_POOL_PART
-#define PT_POOL_PART 4           // one run in PT_POOL_PART is in the common pool
+#ifndef PT_POOL_ALL_FROM
+#define PT_POOL_ALL_FROM 512     // a launch with this many runs per workgroup pools all of them, a smaller one a quarter
 #endif
 #ifndef PT_SAMPLE_WAVES
 #define PT_SAMPLE_WAVES PT_FUSE_WAVES
@@ -1469,20 +1469,21 @@ __global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_SAMPLE_WAVES) k_sample_t
   ShadeCtx cx{sc, cfg, wf, sCnt, T, segCap, segCap};
   cx.segCapHit = wf.capHit / PT_SEGS;
   uint32_t culled = 0, hits = 0, mine = 0;
-  // A workgroup's own runs go to whichever of its waves is free next.  The last quarter of the runs is a pool that all
-  // workgroups take from when their own are done (wf.runPool; PT_POOL_COUNTERS counters that deal out every
-  // PT_POOL_COUNTERS-th run of the pool each, a workgroup moves on to the next counter when one is used up): the
-  // workgroups' own shares differ by several per cent in the vertices they hold, and a launch ends with its slowest
-  // workgroup.  A pooled run is taken only while the region has room for it and for every run the workgroup's waves
-  // are working on, each counted with all the hits it can append (perRun).  The region holds more than a full share
-  // of such runs, so a workgroup declines only after it has done a share, and some workgroup can always take what is
-  // left.
+  // A workgroup's own runs go to whichever of its waves is free next.  The other runs are a pool that all workgroups
+  // take from, PT_POOL_CHUNK at a time, when their own are done (wf.runPool; PT_POOL_COUNTERS counters that deal out
+  // every PT_POOL_COUNTERS-th run of the pool each, a workgroup moves on to the next counter when one is used up):
+  // fixed shares differ by several per cent in the vertices they hold, and a launch ends with its slowest workgroup.
+  // A large launch pools every run; a small one (a wave gets to do a handful of runs) keeps three quarters as fixed
+  // shares, taken from the counter in LDS, because a piece of four is a large part of such a wave's work.
+  // A piece is taken only while the region has room for it and for every run the workgroup's waves are working on,
+  // each counted with all the hits it can append (perRun).  The region holds more than a full share of such runs plus
+  // a piece, so a workgroup declines only after it has done a share, and some workgroup can always take what is left.
   __shared__ uint32_t sNextRun, sBusy, sUsedUp;
   if (threadIdx.x == 0) { sNextRun = 0; sBusy = 0; sUsedUp = 0; }
   __syncthreads();
   const uint32_t perRun = (cfg.mode == 1 ? cfg.numIndirect : 0u) * 64u, cap = segsPer * cx.segCapHit, share = (runs + G - 1) / G;
   const bool pooled = wf.runPool && (perRun == 0 || cap / perRun >= share + PT_POOL_CHUNK);
-  const uint32_t own = pooled ? share - share / PT_POOL_PART : share, firstPooled = G * own;
+  const uint32_t own = !pooled ? share : share >= PT_POOL_ALL_FROM ? 0u : share - share / 4, firstPooled = G * own;
   uint32_t pending = 0, pendingRun = 0;                       // the rest of the piece this wave took from the pool
   for (;;) {
     uint32_t run = PT_NONE;

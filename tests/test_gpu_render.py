@@ -437,12 +437,14 @@ def test_shading_that_traces_its_own_rays_equals_the_queued_path(require_gpu, na
     assert (sb.kernelLaunches[k.index('occluded')] > 0) == bool(sky) and (sb.kernelLaunches[k.index('connect')] > 0) == lights
 
 
-@pytest.mark.parametrize('name,sky,mode', [('chest1', 1, 1), ('cornell-box', 1, 1), ('cornell-box', 0, 0)])
-def test_samples_taken_from_the_common_pool_equal_the_workgroups_own_shares(require_gpu, name, sky, mode):
-    """The one-kernel-per-sample path on a frame large enough for the pool (a quarter of the 64-sample runs, taken by
-    whichever workgroup is free): same bits and counters as with every workgroup keeping to its own share
-    (PT_FLAG_STATIC_RUNS) and as the queued path, over two batches (the pool's counters are cleared in between)."""
-    W, H, spp = 512, 384, 10
+@pytest.mark.parametrize('name,sky,mode,W,H,spp', [('chest1', 1, 1, 512, 384, 10), ('cornell-box', 1, 1, 512, 384, 10),
+                                                   ('cornell-box', 0, 0, 512, 384, 10), ('chest1', 1, 1, 1024, 768, 44),
+                                                   ('cornell-box', 1, 1, 1024, 768, 44)])
+def test_samples_taken_from_the_common_pool_equal_the_workgroups_own_shares(require_gpu, name, sky, mode, W, H, spp):
+    """The one-kernel-per-sample path on frames large enough for the pool of 64-sample runs that whichever workgroup
+    is free takes from (the smaller frame pools a quarter of its runs, the larger one all of them): same bits and
+    counters as with every workgroup keeping to its own share (PT_FLAG_STATIC_RUNS) and as the queued path, over two
+    batches (the pool's counters are cleared in between)."""
     out = []
     for flags in (0, P.PT_FLAG_STATIC_RUNS, P.PT_FLAG_NO_FUSE):
         pt = make_tracer(name, W, H, has_sky=sky, mode=mode, seed=5, max_depth=3, flags=flags)
