@@ -1495,7 +1495,7 @@ __global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_SAMPLE_WAVES) k_sample_t
         if (k < own) {
           run = blockIdx.x + G * k;
           if (run < runs) { got = 1; atomicAdd(&sBusy, 1u); }
-        } else if (pooled) {
+        } else if (pooled && firstPooled < runs) {
           const uint32_t busy = atomicAdd(&sBusy, (uint32_t)PT_POOL_CHUNK) + PT_POOL_CHUNK;
           if (atomicAdd(&sCnt[0], 0u) + busy * perRun <= cap) {
             for (;;) {
