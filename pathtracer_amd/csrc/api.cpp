@@ -481,7 +481,7 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
   // hit queue of stage s + 1, whose records lie in the other pair of arrays (odd stages: hitA/hitB, even: rayO/rayD).
   float4* const pairA[2] = {ws.wf.rayO, ws.wf.hitA};
   float4* const pairB[2] = {ws.wf.rayD, ws.wf.hitB};
-  auto fusedStage = [&](uint32_t s, bool primary, bool last) {
+  auto fusedStage = [&](uint32_t s, bool primary) {
     bind(s);
     wf.round = primary ? 0u : s - 2u;
     wf.hitA = pairA[s & 1u]; wf.hitB = pairB[s & 1u];
@@ -493,7 +493,7 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
       scan((size_t)s * perStage, 1);
     }
     { Timed t(h, PT_K_SHADE); launchShade(lc, h->dsc, dc, pm, h->acc, wf, primary); t.done(); }
-    if (dc.mode == 1 && !last) scan((size_t)(s + 1) * perStage, 1);
+    // (no scan of what it appended: the traced shading of the next stage scans its queue itself)
   };
   uint32_t nslots = pm.npix * pm.k;
   h->st.raysPrimary += nslots; h->st.samples += nslots;
@@ -504,10 +504,8 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
     wf.hitOutA = pairA[0]; wf.hitOutB = pairB[0];
     if (dc.mode == 1) wf.rayOut = ws.hostMetas[(size_t)2 * perStage];
     { Timed t(h, PT_K_SHADE); launchSampleTraced(lc, h->box, ws.masks, h->dsc, dc, pm, h->acc, nslots, wf); t.done(); }
-    if (dc.mode == 1) {
-      scan((size_t)2 * perStage, 1);
-      for (uint32_t round = 0; round <= dc.maxDepth; round++) fusedStage(round + 2, false, round == dc.maxDepth);
-    }
+    if (dc.mode == 1)
+      for (uint32_t round = 0; round <= dc.maxDepth; round++) fusedStage(round + 2, false);
     { Timed t(h, PT_K_ACCUM); launchAccumulate(lc, ws.masks, dc, pm, h->acc, wf, h->dsc); t.done(); }
     HIPCHECK(hipGetLastError());
     return;
@@ -536,9 +534,9 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
   { Timed t(h, PT_K_OTHER); launchRaygen(lc, h->box, ws.masks, dc, pm, h->acc, nslots, wf); t.done(); }
   scan(1, 1);
   if (wf.fuse) {
-    fusedStage(1, true, false);
+    fusedStage(1, true);
     if (dc.mode == 1)
-      for (uint32_t round = 0; round <= dc.maxDepth; round++) fusedStage(round + 2, false, round == dc.maxDepth);
+      for (uint32_t round = 0; round <= dc.maxDepth; round++) fusedStage(round + 2, false);
   } else if (dc.mode == 0 && envDirect(dc, h->dsc, true) && !lc.countVisits && !(h->cfg.flags & PT_FLAG_NO_FUSE)) {
     // a vertex spawns nothing but its sun and sky ray: the kernel that traces them shades the hit itself
     bind(1);

@@ -454,6 +454,33 @@ __global__ void __launch_bounds__(1024) k_scan(const QMeta* __restrict__ metas, 
   q.start[tid] = s;
 }
 
+// The scan done by a consumer itself: every workgroup of a launch of PT_SEGS block-tasks works out the prefix sums of
+// the PT_SEGS counts in its LDS (sp[PT_SEGS + 1]; wsum: one word per wave) and its own task from them -- 4 KB read per
+// workgroup instead of a k_scan launch between producer and consumer (where the queues are nearly empty, the launch
+// and the gaps around it cost more than the kernels between them run).  Same numbers as k_scan writes.
+__device__ __forceinline__ Task scanOwnTask(const uint32_t* __restrict__ count, uint32_t* sp, uint32_t* wsum, uint32_t T) {
+  const uint32_t per = PT_SEGS / blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t c[4], sum = 0;                                                  // workgroups of 256 threads or more
+  for (uint32_t k = 0; k < 4; k++) { c[k] = k < per ? count[tid * per + k] : 0u; sum += c[k]; }
+  uint32_t x = sum;
+  for (int off = 1; off < 64; off <<= 1) { uint32_t y = __shfl_up(x, off); if (lane >= (uint32_t)off) x += y; }
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  uint32_t excl = x - sum;
+  for (uint32_t w = 0; w < wave; w++) excl += wsum[w];
+  for (uint32_t k = 0; k < 4; k++) if (k < per) { sp[tid * per + k] = excl; excl += c[k]; }
+  if (tid == blockDim.x - 1) sp[PT_SEGS] = excl;
+  __syncthreads();
+  const uint32_t total = sp[PT_SEGS], P = dense64(total);
+  Task t; t.begin = T * P; t.end = min(t.begin + P, total); t.seg = PT_SEGS - 1;
+  if (t.begin < total) {
+    uint32_t lo = 0, hi = PT_SEGS;                       // invariant: sp[lo] <= begin < sp[hi]
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (sp[mid] <= t.begin) lo = mid; else hi = mid; }
+    t.seg = lo;
+  }
+  return t;
+}
+
 // Physical index of flat entry j for the traversal kernels' lanes.  The lane keeps the bounds of the segment its
 // last entry was in (consecutive chunks of a wave come from the same 2048 entries, i.e. nearly always the same
 // segment) and searches again, from the hint `seg` (which may be off in either direction), only when j is outside.
@@ -1368,12 +1395,18 @@ __device__ __forceinline__ void shadeBody(const DevScene& sc, const DevCfg& cfg,
   uint32_t segCap = wf.capQueue / PT_SEGS;
   ShadeCtx cx{sc, cfg, wf, sCnt, T, segCap, segCap};
   cx.segCapHit = wf.capHit / PT_SEGS;
-  Task tk = taskOf(wf.hitQ, T);
-  SegCursor seg = segCursor(wf.hitQ, tk.seg);
+  // the traced shading of chain hits reads a queue that another launch of these kernels filled, and scans it itself
+  constexpr bool OWN_SCAN = FUSE && !PRIMARY;
+  __shared__ uint32_t sPrefix[OWN_SCAN ? PT_SEGS + 1 : 1], sWaveSum[16];
+  QMeta hitQ = wf.hitQ;
+  Task tk;
+  if constexpr (OWN_SCAN) { tk = scanOwnTask(wf.hitQ.count, sPrefix, sWaveSum, T); hitQ.prefix = sPrefix; }
+  else tk = taskOf(hitQ, T);
+  SegCursor seg = segCursor(hitQ, tk.seg);
   const FastDiv divCap = wf.divCap;
   if (T == 0 && threadIdx.x == 0) {
-    statAdd(wf.stats, STAT_HITS, (unsigned long long)wf.hitQ.prefix[PT_SEGS]);
-    if (PRIMARY) statAdd(wf.stats, STAT_HITS_PRIMARY, (unsigned long long)wf.hitQ.prefix[PT_SEGS]);
+    statAdd(wf.stats, STAT_HITS, (unsigned long long)hitQ.prefix[PT_SEGS]);
+    if (PRIMARY) statAdd(wf.stats, STAT_HITS_PRIMARY, (unsigned long long)hitQ.prefix[PT_SEGS]);
   }
   for (uint32_t base = tk.begin; base < tk.end; base += blockDim.x) {
     uint32_t j = base + threadIdx.x;
@@ -1383,7 +1416,7 @@ __device__ __forceinline__ void shadeBody(const DevScene& sc, const DevCfg& cfg,
     uint32_t matTag = 0;                     // material index + 1: marks the slot as a view-ray hit (k_accumulate)
     Rng g; g.s0 = 1; g.s1 = 0;
     if (active) {
-      uint32_t e = physIndex(wf.hitQ, j, seg, wf.capHit / PT_SEGS);
+      uint32_t e = physIndex(hitQ, j, seg, wf.capHit / PT_SEGS);
       float4 ha = wf.hitA[e], hb = wf.hitB[e];
       hitPos = xyz(ha); laneSlot = f2u(hb.z);
       uint32_t tri = f2u(ha.w);
