@@ -119,7 +119,7 @@ struct PtHandle {
   DevBuf dTex; bool texDirty = true;   // TriangleData.tex in input order, uploaded at the first texcoord trace
   ViewMasks masks() const { return maskUsable ? ViewMasks{dMask.as<uint32_t>(), dSkyMask.as<uint32_t>()} : ViewMasks{nullptr, nullptr}; }
   DevBuf bMetaDesc; std::vector<QMeta> metas;     // queue descriptors: device copy and host copy, stage-major
-  Wavefront wf{}; uint32_t wfKinds = 0, wfRounds = 0;
+  Wavefront wf{}; uint32_t wfKinds = 0, wfRounds = 0; bool wfLean = false;
   // ptgpu_render_noalloc: address of the static scratch array on this handle's device, and the host copy of the
   // queue descriptors laid over it (sized at creation for the largest maxDepth, so that the call allocates nothing)
   unsigned char* scratchDev = nullptr; std::vector<QMeta> metasNoAlloc;
@@ -344,14 +344,31 @@ void uploadScene(PtHandle* h) {
 
 uint32_t numKinds(const PtHandle* h) { return h->dsc.numLightGroups + 1; }
 
+// Whether the batches of this handle run the shading that traces the rays it spawns (kernels.h: Wavefront::fuse), as far
+// as scene and configuration decide it: scene and shading tables small enough to share a workgroup's LDS, a tree the
+// kernels' stacks hold, and some ray to spawn at all.
+bool sceneFusable(const PtHandle* h) {
+  const PtConfig& c = h->cfg;
+  if (c.flags & (PT_FLAG_NO_FUSE | PT_FLAG_COUNT_VISITS)) return false;     // visits are counted by the traversal kernels proper
+  const uint32_t tables = shadeTableBytes(h->dsc);
+  if (!h->dsc.ldsBytes || !tables || h->dsc.ldsBytes + tables > PT_FUSE_LDS_BYTES) return false;
+  const bool chains = c.mode == 1 && c.numIndirect > 0;
+  return chains || c.hasSky || (c.hasLights && h->dsc.numLightGroups);
+}
+
 void ensureWavefront(PtHandle* h) {
   const PtConfig& c = h->cfg;
+  // Lean: every batch is one whole-sample launch plus traced shading, which use neither the view-ray queue nor the
+  // shadow queues (more than a third of the state in mode 1), and the default batch is twice as large for it: a
+  // batch costs about 0.1 ms of launches, gaps and tails whatever its size (chest1 1080p mode 1, ms per 1024 spp: 64 Mi
+  // slots 64.0, 128 Mi 60.9, 256 Mi 59.0).
+  const bool lean = sceneFusable(h) && !(c.flags & PT_FLAG_QUEUED_VIEW_RAYS);
   // Large batches: every launch ends with a tail in which the last waves finish alone, and a batch is ~10 launches.
   // Measured on the 1080p teapot frame (ms per 256 spp): 4 M slots 70, 16 M 31.6, 32 M 28.0, 64 M 25.1, 128 M 24.5,
   // 256 M 23.7, 512 M 24.0.
   // HBM has room: 128 B per slot in mode 0 without light groups (256 M slots = 34 GB), ~0.9 KB in mode 1 with
   // 5 indirect chains (64 M slots = 60 GB; chest1 1080p mode 1, ms per 64 spp: 32 M 15.1, 64 M 13.6).
-  uint64_t want = c.batchSlots ? c.batchSlots : (c.mode == 1 ? (1u << 26) : (1u << 28));
+  uint64_t want = c.batchSlots ? c.batchSlots : (c.mode == 1 ? (lean ? 1u << 27 : 1u << 26) : (1u << 28));
   uint64_t frame = (uint64_t)c.width * c.height;
   // no point in more slots than 256 samples of the whole frame; a multiple of 64 * PT_SEGS so that every block-task's
   // share of a full batch is whole waves and fits its output segment
@@ -361,10 +378,12 @@ void ensureWavefront(PtHandle* h) {
   uint32_t lanes = 1 + NI;
   if (!c.batchSlots) {       // the default yields to the memory that is actually free (the caller may hold most of it)
     // decided once per shape of the wavefront state, not per render call
-    if (h->wf.capSlots && h->wf.lanes == lanes && h->wfKinds == numKinds(h) && h->wfRounds == (c.mode == 1 ? c.maxDepth + 4 : 2)) return;
+    if (h->wf.capSlots && h->wf.lanes == lanes && h->wfKinds == numKinds(h) && h->wfRounds == (c.mode == 1 ? c.maxDepth + 4 : 2) &&
+        h->wfLean == lean) return;
     size_t freeB = 0, totalB = 0;
     HIPCHECK(hipMemGetInfo(&freeB, &totalB));
-    uint64_t perSlot = 16 + 16ull * lanes + (NI ? 24ull * lanes : 0) + (uint64_t)std::max(1u, NI) * (32 + (NI ? 32 : 0) + 48ull * numKinds(h) + 16);
+    uint64_t perSlot = 16ull * lanes + (NI ? 24ull * lanes : 0) + (uint64_t)std::max(1u, NI) * (32 + (NI ? 32 : 0));
+    if (!lean) perSlot += 16 + (uint64_t)std::max(1u, NI) * (48ull * numKinds(h) + 16);
     uint64_t held = h->wf.capSlots ? (uint64_t)h->wf.capSlots * perSlot : 0;       // what this handle would give back
     while (want > gran && want * perSlot > (freeB + held) / 2) want /= 2;
   }
@@ -373,9 +392,10 @@ void ensureWavefront(PtHandle* h) {
   if (capQueue > 0x7FFFFFFFull || (uint64_t)capSlots * lanes > 0xFFFFFFFFull) fail(PT_E_INVALID, "batchSlots * numIndirect too large");
   uint32_t kinds = numKinds(h), rounds = c.mode == 1 ? c.maxDepth + 4 : 2;
   Wavefront& w = h->wf;
-  if (w.capSlots == capSlots && w.capQueue == (uint32_t)capQueue && w.lanes == lanes && h->wfKinds == kinds && h->wfRounds == rounds) return;
+  if (w.capSlots == capSlots && w.capQueue == (uint32_t)capQueue && w.lanes == lanes && h->wfKinds == kinds && h->wfRounds == rounds &&
+      h->wfLean == lean) return;
   HIPCHECK(hipStreamSynchronize(h->stream));
-  h->bSlotQ.alloc((uint64_t)capSlots * 16);
+  h->bSlotQ.alloc(lean ? 16 : (uint64_t)capSlots * 16);
   uint64_t capHit = capQueue + (uint64_t)PT_SEGS * PT_HIT_SLACK;
   h->bHitA.alloc(capHit * 16); h->bHitB.alloc(capHit * 16);
   // indirect rays only; as large as the hit arrays, so that the fused shading can use the two pairs alternately as the
@@ -386,10 +406,10 @@ void ensureWavefront(PtHandle* h) {
   HIPCHECK(hipMemset(h->bLacc.p, 0, (uint64_t)lanes * capSlots * 16));
   h->bThr.alloc(NI ? (uint64_t)lanes * capSlots * 16 : 16);
   h->bRng.alloc(NI ? (uint64_t)lanes * capSlots * 8 : 16);
-  h->bShO.alloc((uint64_t)kinds * capQueue * 16);
-  h->bShD.alloc((uint64_t)kinds * capQueue * 16);
-  h->bShW.alloc((uint64_t)kinds * capQueue * 16);
-  h->bShX.alloc(capQueue * 16);
+  h->bShO.alloc(lean ? 16 : (uint64_t)kinds * capQueue * 16);
+  h->bShD.alloc(lean ? 16 : (uint64_t)kinds * capQueue * 16);
+  h->bShW.alloc(lean ? 16 : (uint64_t)kinds * capQueue * 16);
+  h->bShX.alloc(lean ? 16 : capQueue * 16);
   // queue bookkeeping: stage s owns 2 + PT_MAX_KINDS queues: [0] the hit queue its extend fills, [1] the ray queue
   // and [2 + kind] the shadow queues its shade fills
   const uint32_t perStage = 2 + PT_MAX_KINDS;
@@ -412,7 +432,7 @@ void ensureWavefront(PtHandle* h) {
   w.stats = h->bStats.as<unsigned long long>();
   w.capSlots = capSlots; w.capQueue = (uint32_t)capQueue; w.capHit = (uint32_t)capHit; w.lanes = lanes;
   w.rayCap = NI ? (uint32_t)capHit : 0u; w.hitOutA = w.hitOutB = nullptr; w.fuse = 0; w.chainMask = 0;
-  h->wfKinds = kinds; h->wfRounds = rounds;
+  h->wfKinds = kinds; h->wfRounds = rounds; h->wfLean = lean;
 }
 
 // Shadow rays of one vertex generation: light groups by Scene.trace, sun and sky (one queue) by Scene.hitsNothing.
@@ -437,13 +457,9 @@ std::atomic<uint32_t> g_batchTag{0};
 // Whether this batch runs the shading variant that traces the rays it spawns (kernels.h: Wavefront::fuse): scene and
 // shading tables small enough to share a shade workgroup's LDS and, for the chains, ray arrays as large as the hit arrays.
 uint32_t fuseBits(const PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, const Wavefront& wf) {
-  if (h->cfg.flags & PT_FLAG_NO_FUSE) return 0;
-  if (lc.countVisits) return 0;                       // visits are counted by the traversal kernels proper
-  const uint32_t tables = shadeTableBytes(h->dsc);
-  if (!h->dsc.ldsBytes || !tables || h->dsc.ldsBytes + tables > PT_FUSE_LDS_BYTES) return 0;
+  if (!sceneFusable(h) || lc.countVisits) return 0;
   const bool chains = dc.mode == 1 && dc.numIndirect > 0;
   if (chains && wf.rayCap < wf.capHit) return 0;
-  if (!chains && !dc.hasSky && !(dc.hasLights && h->dsc.numLightGroups)) return 0;      // no ray is spawned at all
   return 1u;
 }
 
