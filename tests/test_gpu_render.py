@@ -460,6 +460,33 @@ def test_samples_taken_from_the_common_pool_equal_the_workgroups_own_shares(requ
             assert getattr(sa, f) == getattr(sx, f), f
 
 
+def test_wavefront_state_follows_the_path_the_scene_takes(require_gpu):
+    """A handle whose scene takes the one-kernel-per-sample path keeps neither the view-ray queue nor the shadow queues.
+    The same handle switched to the queued path (ptgpu_set_config), back again, and given a scene too large for that
+    path (the teapot) renders the same bits as fresh handles do."""
+    from conftest import CAMERAS, UP, model_path
+    W, H, spp = 128, 96, 5
+
+    def fresh(name, flags):
+        t = make_tracer(name, W, H, has_sky=1, mode=1, seed=9, max_depth=3, flags=flags)
+        t.render_frame(spp)
+        px = t.read_pixels(); t.close()
+        return px['sum'].view(np.uint32)
+
+    want_small, want_big = fresh('chest1', 0), fresh('teapot', 0)
+    assert np.array_equal(want_small, fresh('chest1', P.PT_FLAG_NO_FUSE))
+    pt = make_tracer('chest1', W, H, has_sky=1, mode=1, seed=9, max_depth=3)
+    for flags in (0, P.PT_FLAG_NO_FUSE, 0, P.PT_FLAG_QUEUED_VIEW_RAYS, 0):
+        pt.set_config(flags=flags)
+        pt.clear_pixels(); pt.render_frame(spp)
+        assert np.array_equal(pt.read_pixels()['sum'].view(np.uint32), want_small), flags
+    pt.Scene(model_path('teapot'))
+    pt.set_camera(P.Camera(30.0, H / W).setTransform(CAMERAS['teapot'][0], CAMERAS['teapot'][1], UP))
+    pt.clear_pixels(); pt.render_frame(spp)
+    assert np.array_equal(pt.read_pixels()['sum'].view(np.uint32), want_big)
+    pt.close()
+
+
 @pytest.mark.parametrize('flags', [0, P.PT_FLAG_NO_LDS_SCENE])
 def test_traversal_kernel_that_shades_its_hits_equals_the_queued_path(require_gpu, flags):
     """Mode 0, sky, no light group, a scene too large for the shading kernel's LDS (the teapot): the kernel that traces
