@@ -1675,9 +1675,9 @@ __global__ void __launch_bounds__(256) k_accumulate(ViewMasks masks, DevCfg cfg,
     acc[gp] = a;
     return;
   }
-  for (uint32_t s = 0; s < pm.k; s++) {
-    uint32_t slot = s * pm.npix + lp;
-    float4 L = wf.Lacc[slot];
+  // the records of four samples are requested before the first is looked at: the additions below stay in sample
+  // order, but a lane's loads no longer wait for each other (the launch reads 16 B per sample and is bound by HBM)
+  auto addSample = [&](float4 L, uint32_t slot) {
     V3 add = xyz(L);
     const uint32_t tagWord = f2u(L.w);
     if (tagWord) {
@@ -1697,7 +1697,13 @@ __global__ void __launch_bounds__(256) k_accumulate(ViewMasks masks, DevCfg cfg,
       }
     }
     a.x += add.x; a.y += add.y; a.z += add.z; a.w += 1.0f;
+  };
+  uint32_t s = 0, slot = lp;
+  for (; s + 4 <= pm.k; s += 4, slot += 4 * pm.npix) {
+    const float4 L0 = wf.Lacc[slot], L1 = wf.Lacc[slot + pm.npix], L2 = wf.Lacc[slot + 2 * pm.npix], L3 = wf.Lacc[slot + 3 * pm.npix];
+    addSample(L0, slot); addSample(L1, slot + pm.npix); addSample(L2, slot + 2 * pm.npix); addSample(L3, slot + 3 * pm.npix);
   }
+  for (; s < pm.k; s++, slot += pm.npix) addSample(wf.Lacc[slot], slot);
   acc[gp] = a;
 }
 
