@@ -509,7 +509,7 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
       scan((size_t)s * perStage, 1);
     }
     { Timed t(h, PT_K_SHADE); launchShade(lc, h->dsc, dc, pm, h->acc, wf, primary); t.done(); }
-    // (no scan of what it appended: the traced shading of the next stage scans its queue itself)
+    // (no scan of what it appended: the traced shading of chain hits takes its queue segment by segment)
   };
   uint32_t nslots = pm.npix * pm.k;
   h->st.raysPrimary += nslots; h->st.samples += nslots;
@@ -520,8 +520,7 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
     wf.hitOutA = pairA[0]; wf.hitOutB = pairB[0];
     if (dc.mode == 1) wf.rayOut = ws.hostMetas[(size_t)2 * perStage];
     { Timed t(h, PT_K_SHADE); launchSampleTraced(lc, h->box, ws.masks, h->dsc, dc, pm, h->acc, nslots, wf); t.done(); }
-    if (dc.mode == 1)
-      for (uint32_t round = 0; round <= dc.maxDepth; round++) fusedStage(round + 2, false);
+    if (dc.mode == 1) fusedStage(2, false);                // one launch goes through all bounce rounds
     { Timed t(h, PT_K_ACCUM); launchAccumulate(lc, ws.masks, dc, pm, h->acc, wf, h->dsc); t.done(); }
     HIPCHECK(hipGetLastError());
     return;
@@ -551,8 +550,7 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
   scan(1, 1);
   if (wf.fuse) {
     fusedStage(1, true);
-    if (dc.mode == 1)
-      for (uint32_t round = 0; round <= dc.maxDepth; round++) fusedStage(round + 2, false);
+    if (dc.mode == 1) fusedStage(2, false);
   } else if (dc.mode == 0 && envDirect(dc, h->dsc, true) && !lc.countVisits && !(h->cfg.flags & PT_FLAG_NO_FUSE)) {
     // a vertex spawns nothing but its sun and sky ray: the kernel that traces them shades the hit itself
     bind(1);

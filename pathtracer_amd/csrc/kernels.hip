@@ -454,33 +454,6 @@ __global__ void __launch_bounds__(1024) k_scan(const QMeta* __restrict__ metas, 
   q.start[tid] = s;
 }
 
-// The scan done by a consumer itself: every workgroup of a launch of PT_SEGS block-tasks works out the prefix sums of
-// the PT_SEGS counts in its LDS (sp[PT_SEGS + 1]; wsum: one word per wave) and its own task from them -- 4 KB read per
-// workgroup instead of a k_scan launch between producer and consumer (where the queues are nearly empty, the launch
-// and the gaps around it cost more than the kernels between them run).  Same numbers as k_scan writes.
-__device__ __forceinline__ Task scanOwnTask(const uint32_t* __restrict__ count, uint32_t* sp, uint32_t* wsum, uint32_t T) {
-  const uint32_t per = PT_SEGS / blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  uint32_t c[4], sum = 0;                                                  // workgroups of 256 threads or more
-  for (uint32_t k = 0; k < 4; k++) { c[k] = k < per ? count[tid * per + k] : 0u; sum += c[k]; }
-  uint32_t x = sum;
-  for (int off = 1; off < 64; off <<= 1) { uint32_t y = __shfl_up(x, off); if (lane >= (uint32_t)off) x += y; }
-  if (lane == 63) wsum[wave] = x;
-  __syncthreads();
-  uint32_t excl = x - sum;
-  for (uint32_t w = 0; w < wave; w++) excl += wsum[w];
-  for (uint32_t k = 0; k < 4; k++) if (k < per) { sp[tid * per + k] = excl; excl += c[k]; }
-  if (tid == blockDim.x - 1) sp[PT_SEGS] = excl;
-  __syncthreads();
-  const uint32_t total = sp[PT_SEGS], P = dense64(total);
-  Task t; t.begin = T * P; t.end = min(t.begin + P, total); t.seg = PT_SEGS - 1;
-  if (t.begin < total) {
-    uint32_t lo = 0, hi = PT_SEGS;                       // invariant: sp[lo] <= begin < sp[hi]
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (sp[mid] <= t.begin) lo = mid; else hi = mid; }
-    t.seg = lo;
-  }
-  return t;
-}
-
 // Physical index of flat entry j for the traversal kernels' lanes.  The lane keeps the bounds of the segment its
 // last entry was in (consecutive chunks of a wave come from the same 2048 entries, i.e. nearly always the same
 // segment) and searches again, from the hint `seg` (which may be off in either direction), only when j is outside.
@@ -1097,6 +1070,8 @@ struct ShadeCtx {
   // FUSE (rays traced where they are made, see k_shade): segment size of the hit queue the continuation rays' hits go
   // to, and what the lane traced (indirect rays, light-sample rays, sun/sky rays, vertices with a sun or sky ray)
   uint32_t segCapHit = 0; uint32_t nInd = 0, nLight = 0, nOccl = 0, nEnv = 0;
+  float4* outA = nullptr; float4* outB = nullptr;      // the hit records the continuation rays' hits go to
+  uint32_t segBits = 0;                                // ... dealt in turn to the 1 << segBits segments from T on
 };
 
 // One computeLindirect head (rendering.d:378-385): Russian roulette, direction, ray; appended to ray queue qOut.
@@ -1130,9 +1105,9 @@ __device__ __forceinline__ bool bounce(ShadeCtx& cx, bool active, Rng& g, uint32
     }
     uint32_t idx = waveAppend(isHit, &cx.sCnt[0]);
     if (isHit) {
-      uint32_t e = cx.T * cx.segCapHit + idx;
-      cx.wf.hitOutA[e] = f4(o + dir * h.t, u2f(h.tri));
-      cx.wf.hitOutB[e] = make_float4(h.u, h.v, u2f(laneSlot), FIRST ? u2f(firstMat) : 0.0f);
+      uint32_t e = (cx.T + (idx & ((1u << cx.segBits) - 1u))) * cx.segCapHit + (idx >> cx.segBits);
+      cx.outA[e] = f4(o + dir * h.t, u2f(h.tri));
+      cx.outB[e] = make_float4(h.u, h.v, u2f(laneSlot), FIRST ? u2f(firstMat) : 0.0f);
       if (!FIRST) {
         cx.wf.thr[laneSlot] = f4(T * color, u2f(depth + 1));
         cx.wf.rng[laneSlot] = make_uint2(g.s0, g.s1);
@@ -1394,20 +1369,29 @@ __device__ __forceinline__ void shadeBody(const DevScene& sc, const DevCfg& cfg,
   uint32_t T = blockIdx.x;
   uint32_t segCap = wf.capQueue / PT_SEGS;
   ShadeCtx cx{sc, cfg, wf, sCnt, T, segCap, segCap};
-  cx.segCapHit = wf.capHit / PT_SEGS;
-  // the traced shading of chain hits reads a queue that another launch of these kernels filled, and scans it itself
-  constexpr bool OWN_SCAN = FUSE && !PRIMARY;
-  __shared__ uint32_t sPrefix[OWN_SCAN ? PT_SEGS + 1 : 1], sWaveSum[16];
-  QMeta hitQ = wf.hitQ;
-  Task tk;
-  if constexpr (OWN_SCAN) { tk = scanOwnTask(wf.hitQ.count, sPrefix, sWaveSum, T); hitQ.prefix = sPrefix; }
-  else tk = taskOf(hitQ, T);
-  SegCursor seg = segCursor(hitQ, tk.seg);
-  const FastDiv divCap = wf.divCap;
-  if (T == 0 && threadIdx.x == 0) {
-    statAdd(wf.stats, STAT_HITS, (unsigned long long)hitQ.prefix[PT_SEGS]);
-    if (PRIMARY) statAdd(wf.stats, STAT_HITS_PRIMARY, (unsigned long long)hitQ.prefix[PT_SEGS]);
+  cx.segCapHit = wf.capHit / PT_SEGS; cx.outA = wf.hitOutA; cx.outB = wf.hitOutB;
+  // OWN_SEGMENT (the traced shading of chain hits): block-task T shades what segment T of the queue holds -- the
+  // queue was filled by another launch of these kernels, whose workgroups' shares are even enough, and needs no scan --
+  // and goes through all bounce rounds: what the workgroup appended in one round (the hits of its vertices'
+  // continuation rays, in segment T of the other pair of record arrays) is what it shades in the next.  No launch, no
+  // scan and no exchange between rounds; nobody else reads or writes segment T of either pair.
+  constexpr bool OWN_SEGMENT = FUSE && !PRIMARY;
+  const QMeta& hitQ = wf.hitQ;
+  Task tk; SegCursor seg;
+  if constexpr (OWN_SEGMENT) {
+    tk.begin = 0; tk.end = hitQ.count[T]; tk.seg = T; seg.seg = T; seg.lo = 0; seg.hi = tk.end;
+    if (threadIdx.x == 0 && tk.end) statAdd(wf.stats, STAT_HITS, (unsigned long long)tk.end);
+  } else {
+    tk = taskOf(hitQ, T); seg = segCursor(hitQ, tk.seg);
+    if (T == 0 && threadIdx.x == 0) {
+      statAdd(wf.stats, STAT_HITS, (unsigned long long)hitQ.prefix[PT_SEGS]);
+      if (PRIMARY) statAdd(wf.stats, STAT_HITS_PRIMARY, (unsigned long long)hitQ.prefix[PT_SEGS]);
+    }
   }
+  const FastDiv divCap = wf.divCap;
+  uint32_t round = wf.round;
+  const float4* inA = wf.hitA; const float4* inB = wf.hitB;
+  for (;;) {
   for (uint32_t base = tk.begin; base < tk.end; base += blockDim.x) {
     uint32_t j = base + threadIdx.x;
     bool active = j < tk.end;
@@ -1417,7 +1401,7 @@ __device__ __forceinline__ void shadeBody(const DevScene& sc, const DevCfg& cfg,
     Rng g; g.s0 = 1; g.s1 = 0;
     if (active) {
       uint32_t e = physIndex(hitQ, j, seg, wf.capHit / PT_SEGS);
-      float4 ha = wf.hitA[e], hb = wf.hitB[e];
+      float4 ha = inA[e], hb = inB[e];
       hitPos = xyz(ha); laneSlot = f2u(hb.z);
       uint32_t tri = f2u(ha.w);
       if (PRIMARY) {
@@ -1426,7 +1410,7 @@ __device__ __forceinline__ void shadeBody(const DevScene& sc, const DevCfg& cfg,
         sampleIdx = cfg.sampleBase + ((uint32_t)acc[gp].w + s) * cfg.sampleStride;
         g.seed(cfg.seed, gp, sampleIdx, 0);
         g.next(); g.next();                                            // the x and y jitter of getViewRay
-      } else if (wf.round == 0) {
+      } else if (round == 0) {
         // hit of a chain's first ray: what bounce<true> did not store
         uint32_t chain = fdiv(divCap, laneSlot), slot = laneSlot - chain * wf.capSlots;         // chain = 1 + index
         uint32_t s = fdiv(pm.divNpix, slot), lp = slot - s * pm.npix;
@@ -1444,9 +1428,23 @@ __device__ __forceinline__ void shadeBody(const DevScene& sc, const DevCfg& cfg,
     }
     shadeVertex<PRIMARY, LDST, FUSE>(cx, tb, active, hitPos, normal, color, matTag, Tp, depth, g, gp, sampleIdx, laneSlot);
   }
+  if constexpr (!OWN_SEGMENT) break;
+  else {
+    __syncthreads();                                   // the round's appends are counted, its records written
+    const uint32_t n = sCnt[0];
+    if (n == 0 || round >= cfg.maxDepth) break;        // (a vertex deeper than maxDepth spawns nothing, rendering.d:380)
+    __syncthreads();
+    if (threadIdx.x == 0) { sCnt[0] = 0; statAdd(wf.stats, STAT_HITS, (unsigned long long)n); }
+    __syncthreads();
+    round++;
+    float4* const nextA = cx.outA; float4* const nextB = cx.outB;
+    cx.outA = const_cast<float4*>(inA); cx.outB = const_cast<float4*>(inB); inA = nextA; inB = nextB;
+    tk.begin = 0; tk.end = n; seg.seg = T; seg.lo = 0; seg.hi = n;
+  }
+  }
   if constexpr (FUSE) flushTraced(cx);
   __syncthreads();
-  if (threadIdx.x == 0) wf.rayOut.count[T] = sCnt[0];
+  if (threadIdx.x == 0) wf.rayOut.count[T] = OWN_SEGMENT ? 0u : sCnt[0];
   if (threadIdx.x >= 1 && threadIdx.x <= (uint32_t)numKinds) wf.sh[threadIdx.x - 1].count[T] = sCnt[threadIdx.x];
 }
 
@@ -1482,7 +1480,8 @@ __global__ void __launch_bounds__(PT_FUSE_THREADS, PT_FUSE_WAVES) k_shade_traced
 #ifndef PT_SAMPLE_WAVES
 #define PT_SAMPLE_WAVES PT_FUSE_WAVES
 #endif
-static_assert(PT_SEGS % PT_SAMPLE_GROUPS == 0, "a workgroup appends to a whole number of segments");
+static_assert(PT_SEGS % PT_SAMPLE_GROUPS == 0 && ((PT_SEGS / PT_SAMPLE_GROUPS) & (PT_SEGS / PT_SAMPLE_GROUPS - 1)) == 0,
+              "a workgroup appends to a power of two of whole segments");
 __global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_SAMPLE_WAVES) k_sample_traced(SceneBox box, ViewMasks masks, DevScene sc, DevCfg cfg, PixMap pm,
                                                                    const float4* __restrict__ acc, uint32_t nslots, Wavefront wf) {
   __shared__ uint32_t sCnt[1 + PT_MAX_KINDS];
@@ -1500,7 +1499,8 @@ __global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_SAMPLE_WAVES) k_sample_t
   const uint32_t T = blockIdx.x * segsPer;                 // first segment of this workgroup's region
   const uint32_t segCap = wf.capQueue / PT_SEGS;
   ShadeCtx cx{sc, cfg, wf, sCnt, T, segCap, segCap};
-  cx.segCapHit = wf.capHit / PT_SEGS;
+  cx.segCapHit = wf.capHit / PT_SEGS; cx.outA = wf.hitOutA; cx.outB = wf.hitOutB;
+  cx.segBits = 31u - (uint32_t)__builtin_clz(segsPer);       // the consumers take a segment each: the hits go to all of them in turn
   uint32_t culled = 0, hits = 0, mine = 0;
   // A workgroup's own runs go to whichever of its waves is free next.  The other runs are a pool that all workgroups
   // take from, PT_POOL_CHUNK at a time, when their own are done (wf.runPool; PT_POOL_COUNTERS counters that deal out
@@ -1593,8 +1593,8 @@ __global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_SAMPLE_WAVES) k_sample_t
   }
   __syncthreads();
   if (threadIdx.x < segsPer) {
-    const uint32_t n = sCnt[0], before = threadIdx.x * cx.segCapHit;
-    wf.rayOut.count[T + threadIdx.x] = n > before ? min(n - before, cx.segCapHit) : 0u;
+    const uint32_t n = sCnt[0];
+    wf.rayOut.count[T + threadIdx.x] = (n + segsPer - 1u - threadIdx.x) >> cx.segBits;      // hit idx went to segment idx % segsPer
   }
 }
 
