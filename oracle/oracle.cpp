@@ -44,7 +44,7 @@
 //   S10 uniform(a,b) = a + (b-a)*r, r = (x>>8)*2^-24 in [0,1)
 //   S11 Triangle.area = 0.5*|(v1-v0)x(v2-v0)|
 //   S12 A in B (spheres) <=> |cA-cB| + rA <= rB ; Sphere.radius = sqrtf(radiusSquared)
-//   S13 cosf / sinf: one fixed binary64 evaluation rounded once (sincosS13), within 1 ulp of libm
+//   S13 cosf / sinf: one fixed binary32 evaluation (sincosS13), within 1 ulp of libm
 //   S14 powf(x, 1/2.4) of the tone map: one fixed binary64 evaluation rounded once (powInv24S14)
 // Everything else is evaluated left to right as the D source writes it, one IEEE float
 // operation per operator, no contraction (compile with -ffp-contract=off).
@@ -458,26 +458,32 @@ V3 pickRandomLightPoint(const Scene& sc, Rng& gen, uint32_t li) {   // rendering
   }
 }
 
-// cosf / sinf of the reference (rendering.d:309-330), S13: evaluated in binary64 in one fixed order and rounded to
-// binary32 once -- k = rint(x * 2/pi), r = x - k*pi/2 in two pieces, Taylor sin (through r^11) and cos (through
-// r^12) by Horner with fma, quadrant from k -- so that every implementation of this sequence returns the same bits.
-// Within 1 ulp of libm (test_oracle.py); the product evaluates the same sequence (pt_math.h: sincosFixed).
+// cosf / sinf of the reference (rendering.d:309-330), S13: one fixed binary32 evaluation -- k = rint(x * 2/pi),
+// r = x - k*pi/2 with pi/2 in four pieces (the first two short enough for k * piece to be exact), Taylor sin (through
+// r^9) and cos (through r^10) by Horner with fma, quadrant from k -- so that every implementation of this sequence
+// returns the same bits.  Never more than 1 ulp from the correctly rounded value on [0, 100] (every binary32 was
+// checked) and hence within 1 ulp of libm (test_oracle.py); the product evaluates the same sequence
+// (pt_math.h: sincosFixed).
+// g_libmTrig: the library calls the reference makes instead (orc_set_libm_trig; never set by the parity tests -- it
+// exists to bound, over whole images, what the choice of S13 over this host's libm changes).
+bool g_libmTrig = false;
 void sincosS13(float x, float& sn, float& cs) {
-  double xd = (double)x;
-  double k = std::rint(xd * 0.63661977236758134308);
-  double r = std::fma(-k, 1.57079632679489655800, xd);
-  r = std::fma(-k, 6.12323399573676603587e-17, r);
-  double r2 = r * r;
-  static const double SC[5] = {-1.0 / 39916800.0, 1.0 / 362880.0, -1.0 / 5040.0, 1.0 / 120.0, -1.0 / 6.0};
-  static const double CC[6] = {1.0 / 479001600.0, -1.0 / 3628800.0, 1.0 / 40320.0, -1.0 / 720.0, 1.0 / 24.0, -0.5};
-  double ps = SC[0]; for (int i = 1; i < 5; i++) ps = std::fma(ps, r2, SC[i]);
-  double pc = CC[0]; for (int i = 1; i < 6; i++) pc = std::fma(pc, r2, CC[i]);
-  double s = std::fma(r * r2, ps, r), c = std::fma(r2, pc, 1.0);
-  switch ((int)(long long)k & 3) {
-    case 0: sn = (float)s; cs = (float)c; break;
-    case 1: sn = (float)c; cs = (float)(-s); break;
-    case 2: sn = (float)(-s); cs = (float)(-c); break;
-    default: sn = (float)(-c); cs = (float)s; break;
+  if (g_libmTrig) { sn = sinf(x); cs = cosf(x); return; }
+  static const float PIO2[4] = {1.5703125f, 4.837512969970703125e-4f, 7.549790126404332e-8f, -1.7151245100058819e-15f};
+  static const float SC[4] = {2.7557314297e-6f, -1.9841270114e-4f, 8.3333337680e-3f, -1.6666667163e-1f};
+  static const float CC[5] = {-2.7557314297e-7f, 2.4801587642e-5f, -1.3888889225e-3f, 4.1666667908e-2f, -0.5f};
+  float k = std::rint(x * 0.636619772f);
+  float r = x;
+  for (int i = 0; i < 4; i++) r = std::fma(-k, PIO2[i], r);
+  float r2 = r * r;
+  float ps = SC[0]; for (int i = 1; i < 4; i++) ps = std::fma(ps, r2, SC[i]);
+  float pc = CC[0]; for (int i = 1; i < 5; i++) pc = std::fma(pc, r2, CC[i]);
+  float s = std::fma(r * r2, ps, r), c = std::fma(r2, pc, 1.0f);
+  switch ((int)k & 3) {
+    case 0: sn = s; cs = c; break;
+    case 1: sn = c; cs = -s; break;
+    case 2: sn = -s; cs = -c; break;
+    default: sn = -c; cs = s; break;
   }
 }
 V3 angleToLocalDirection(float phi, float psi) {                    // rendering.d:309-314
@@ -856,6 +862,7 @@ void orc_tonemap(const Pixel* pixels, uint32_t count, uint8_t* rgb) {
     }
 }
 // Probes of S13 / S14 and of the direction helpers, for cross-checks against libm and against the device.
+void orc_set_libm_trig(int on) { g_libmTrig = on != 0; }
 void orc_sincos(const float* x, uint32_t n, float* s, float* c) { for (uint32_t i = 0; i < n; i++) sincosS13(x[i], s[i], c[i]); }
 void orc_pow_inv24(const float* x, uint32_t n, float* y) { for (uint32_t i = 0; i < n; i++) y[i] = powInv24S14(x[i]); }
 // angleToDirection(phi, psi, normal) (rendering.d:316-330); a zero normal selects angleToLocalDirection (:309-314).

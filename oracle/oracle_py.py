@@ -55,6 +55,7 @@ def lib():
         L.orc_render_keyed.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_uint32, C.c_int, C.c_void_p]
         L.orc_sincos.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_set_libm_trig.argtypes = [C.c_int]
         L.orc_pow_inv24.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_angle_directions.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_keyed_stream.argtypes = [C.c_uint32] * 5 + [C.c_void_p]
@@ -199,6 +200,12 @@ def keyed_stream(seed, pixel, sample, stream, n):
     out = np.empty(n, np.uint32)
     lib().orc_keyed_stream(seed, pixel, sample, stream, n, _p(out))
     return out
+
+
+def set_libm_trig(on):
+    """Process-wide: the oracle calls this host's sinf / cosf instead of the fixed sequence S13 (for bounding what the
+    choice changes over whole images; parity tests never set it)."""
+    lib().orc_set_libm_trig(int(bool(on)))
 
 
 def sincos(x):

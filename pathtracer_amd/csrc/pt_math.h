@@ -124,39 +124,45 @@ PT_HD float interpolateComponent(float u, float v, float val0, float val1, float
 
 // ------------------------------------------------------------------ sin, cos, pow with one fixed evaluation
 // cosf / sinf (rendering.d:309-330) and powf (main.d:92) are library calls in the reference; two libraries differ
-// in the last bit, and one bit of a direction can flip a visibility decision.  These evaluate in binary64 with an
-// explicit sequence of fma / * / + / rint / IEEE division, rounded to binary32 once, so that host and device (and
-// any restatement that uses the same constants and order) return the same bits.  Error before the final rounding
-// < 1e-11 (sin, cos, |x| <= 1e4) and < 1e-13 relative (pow): the result is the correctly rounded one except in about
-// one case in 10^4, where it is its neighbour.
+// in the last bit, and one bit of a direction can flip a visibility decision.  These evaluate one explicit sequence
+// of fma / * / + / rint (and, for pow, IEEE division), so that host and device (and any restatement that uses the
+// same constants and order) return the same bits.
 //
-// sin and cos of x: k = rint(x * 2/pi); r = x - k * pi/2 (pi/2 = HI + LO); Taylor polynomials in r on [-pi/4, pi/4]
-// (sin through r^11, cos through r^12), Horner with fma from the highest coefficient; quadrant k & 3.
+// sin and cos of x, binary32 throughout (the integrator evaluates them eleven times per shaded vertex, and binary64
+// vector arithmetic runs at half rate with twice the registers): k = rint(x * 2/pi); r = x - k * pi/2 with pi/2 in
+// four parts (Cody-Waite: the first two have 9 and 11 significant bits, so k * part is exact and so is the
+// difference; the last two carry pi/2 to 2^-76, which keeps r accurate when x lies next to a multiple of pi/2);
+// Taylor polynomials in r on [-pi/4, pi/4] (sin through r^9, cos through r^10: truncation < 0.03 ulp), Horner with
+// fma from the highest coefficient; quadrant k & 3.  Checked against the correctly rounded value for EVERY binary32
+// in [0, 100] (scripts/probes/sincos_f32_check.cpp): never more than 1 ulp away, and the correctly rounded value
+// itself for 89 % (sin) and 83 % (cos) of arguments drawn uniformly from [0, 2 pi].
 PT_HD void sincosFixed(float x, float* sinOut, float* cosOut) {
-  const double xd = (double)x;
-  const double k = rint(xd * 0.63661977236758134308);                // 2 / pi
-  double r = fma(-k, 1.57079632679489655800, xd);                    // pi / 2, leading 53 bits
-  r = fma(-k, 6.12323399573676603587e-17, r);                        // pi / 2, next 53 bits
-  const double r2 = r * r;
-  double ps = -1.0 / 39916800.0;                                     // -1/11!
-  ps = fma(ps, r2, 1.0 / 362880.0);                                  //  1/9!
-  ps = fma(ps, r2, -1.0 / 5040.0);                                   // -1/7!
-  ps = fma(ps, r2, 1.0 / 120.0);                                     //  1/5!
-  ps = fma(ps, r2, -1.0 / 6.0);                                      // -1/3!
-  const double s = fma(r * r2, ps, r);
-  double pc = 1.0 / 479001600.0;                                     //  1/12!
-  pc = fma(pc, r2, -1.0 / 3628800.0);                                // -1/10!
-  pc = fma(pc, r2, 1.0 / 40320.0);                                   //  1/8!
-  pc = fma(pc, r2, -1.0 / 720.0);                                    // -1/6!
-  pc = fma(pc, r2, 1.0 / 24.0);                                      //  1/4!
-  pc = fma(pc, r2, -0.5);                                            // -1/2!
-  const double c = fma(r2, pc, 1.0);
-  const int q = (int)(long long)k & 3;
-  const double sq = (q & 1) ? c : s, cq = (q & 1) ? s : c;
-  *sinOut = (float)((q & 2) ? -sq : sq);
-  *cosOut = (float)(((q + 1) & 2) ? -cq : cq);
+  const float k = rintf(x * 0.636619772f);                           // 2 / pi
+  float r = fmaf(-k, 1.5703125f, x);                                 // pi / 2: 0x3FC90000
+  r = fmaf(-k, 4.837512969970703125e-4f, r);                         //         0x39FDA000
+  r = fmaf(-k, 7.549790126404332e-8f, r);                            //         0x33A22169
+  r = fmaf(-k, -1.7151245100058819e-15f, r);                         //         0xA6F72CED
+  const float z = r * r;
+  float ps = 2.7557314297e-6f;                                       //  1/9!
+  ps = fmaf(ps, z, -1.9841270114e-4f);                               // -1/7!
+  ps = fmaf(ps, z, 8.3333337680e-3f);                                //  1/5!
+  ps = fmaf(ps, z, -1.6666667163e-1f);                               // -1/3!
+  const float s = fmaf(r * z, ps, r);
+  float pc = -2.7557314297e-7f;                                      // -1/10!
+  pc = fmaf(pc, z, 2.4801587642e-5f);                                //  1/8!
+  pc = fmaf(pc, z, -1.3888889225e-3f);                               // -1/6!
+  pc = fmaf(pc, z, 4.1666667908e-2f);                                //  1/4!
+  pc = fmaf(pc, z, -0.5f);                                           // -1/2!
+  const float c = fmaf(z, pc, 1.0f);
+  const int q = (int)k & 3;
+  const float sq = (q & 1) ? c : s, cq = (q & 1) ? s : c;
+  *sinOut = (q & 2) ? -sq : sq;
+  *cosOut = ((q + 1) & 2) ? -cq : cq;
 }
 
+// pow: binary64 with an explicit sequence of fma / * / + / rint / IEEE division, rounded to binary32 once (error
+// before the final rounding < 1e-13 relative: the correctly rounded result except in about one case in 10^4, where
+// it is its neighbour).  One evaluation per channel of a displayed pixel, not per sample.
 // x^(1/2.4) for x in (0, 1] (the sRGB curve of drawScreen, main.d:92): x = m * 2^e with m in [sqrt(1/2), sqrt(2));
 // ln m = 2 atanh(f), f = (m - 1) / (m + 1), series through f^13; y = (e ln 2 + ln m) * (1 / 2.4); n = rint(y / ln 2);
 // g = y - n ln 2; exp(g) by Taylor through g^11; result scaled by 2^n.

@@ -196,21 +196,47 @@ def _ulps(a, b):
 
 
 def test_fixed_sincos_and_pow_against_libm():
-    """S13 / S14: the fixed binary64 evaluations of sinf, cosf and powf(x, 1/2.4) stay within 1 ulp of the correctly
-    rounded value (and of this host's libm), on the ranges the integrator and the tone map use."""
+    """S13 / S14: the fixed evaluations of sinf, cosf (binary32) and powf(x, 1/2.4) (binary64, rounded once) stay within
+    1 ulp of the correctly rounded value (and of this host's libm), on the ranges the integrator and the tone map use.
+    (scripts/probes/sincos_f32_check.cpp walks every binary32 in a range; on [0, 100] the bound is 1 ulp as well.)"""
     rng = np.random.default_rng(5)
     x = np.concatenate([rng.uniform(0, 2 * np.pi, 400000), rng.uniform(0, np.pi / 2, 100000),
                         [0.0, np.pi / 2, np.pi, 1.5 * np.pi, 2 * np.pi, np.pi / 2 * 0.99]]).astype(np.float32)
     s, c = oracle_py.sincos(x)
     exact_s = np.sin(x.astype(np.float64)).astype(np.float32); exact_c = np.cos(x.astype(np.float64)).astype(np.float32)
     assert _ulps(s, exact_s).max() <= 1 and _ulps(c, exact_c).max() <= 1
-    assert (s != exact_s).mean() < 1e-4 and (c != exact_c).mean() < 1e-4
+    assert (s != exact_s).mean() < 0.25 and (c != exact_c).mean() < 0.25          # the correctly rounded value for > 4 in 5
     assert _ulps(s, np.sin(x)).max() <= 1 and _ulps(c, np.cos(x)).max() <= 1        # libm's float32 routines
     y = np.concatenate([rng.uniform(0.0031308, 1.0, 400000), [0.0031309, 0.25, 0.5, 1.0]]).astype(np.float32)
     p = oracle_py.pow_inv24(y)
     exact_p = np.power(y.astype(np.float64), 1 / 2.4).astype(np.float32)
     assert _ulps(p, exact_p).max() <= 1 and (p != exact_p).mean() < 1e-4
     assert p[-1] == 1.0
+
+
+def test_fixed_sincos_against_libm_over_whole_images(flats):
+    """What choosing S13 (a fixed sin / cos sequence) over the host's libm changes in an image: the directions differ by
+    at most an ulp, which moves a radiance value in its last bits and, rarely, flips a visibility decision of one
+    sample.  Bounded here per model and mode on the same keyed streams: no difference in which rays are traced beyond
+    a handful, relative RMSE of the image far below the Monte Carlo noise."""
+    W = H = 48
+    try:
+        for name in ('cornell-box', 'teapot', 'chest1'):
+            for mode, spp in ((0, 8), (1, 4)):
+                imgs, counts = [], []
+                for libm in (False, True):
+                    oracle_py.set_libm_trig(libm)
+                    o = make_oracle(flats[name], name, W, H, has_sky=name != 'cornell-box', mode=mode, seed=11)
+                    px = oracle_py.new_pixels(W * H)
+                    _, cn = o.render_keyed(px, 0, spp, nthreads=4, use_tree=False)
+                    imgs.append(px['color'].astype(np.float64)); counts.append(np.asarray(cn[:2], np.int64))
+                rmse = np.sqrt(((imgs[0] - imgs[1]) ** 2).mean()) / max(imgs[0].mean(), 1e-9)
+                # (measured: <= 2e-9 everywhere except cornell mode 1, 6e-3 -- a bounce direction an ulp off moves a
+                # hit point on a wall and with it the 1/d^2 of its light sample; two seeds differ by ~1 at this spp)
+                assert rmse < 2e-2, (name, mode, rmse)
+                assert np.abs(counts[0] - counts[1]).max() <= 1e-4 * counts[0].max() + 4, (name, mode, counts)
+    finally:
+        oracle_py.set_libm_trig(False)
 
 
 def test_keyed_sample_stride_interleaves_ranks(flats):
