@@ -50,11 +50,16 @@ L2_PEAK_GBS = 34500.0                  # aggregate of the eight 4 MiB L2s (micro
 VALU_PEAK_GLANEOPS = 256 * 4 * 32 * 2.4
 # algorithmic bytes (defined on the canonical layout: 32-byte node, 9 floats per triangle)
 B_STREAM_CLOSEST, B_STREAM_ANY, B_NODE, B_TRI = 48.0, 36.0, 32.0, 36.0
-PROFILE_TAG = 'r02'
+PROFILE_TAG = 'r03'
 
 
 def total_rays(st):
     return st.raysPrimary + st.raysLight + st.raysIndirect + st.raysOcclusion
+
+
+def tri_slots(st):
+    """Triangle slots of the scene as uploaded (degenerate triangles are dropped by the builder; an empty scene keeps one)."""
+    return max(1, st.numTriangles)
 
 
 def headless_passes():
@@ -94,65 +99,109 @@ def profile_json(workload):
     return json.load(open(path)), os.path.relpath(path, ROOT)
 
 
-def ceilings(kind, st, visits, ms, launches, pmc, scene_in_lds):
-    """Fractions of the three ceilings a kernel kind can be held against, none of which can exceed 1 by construction of
-    its numerator: HBM (algorithmic bytes that must cross HBM), LDS (node and triangle bytes served from the scene copy
-    in LDS) and vector lane operations (issued vector instructions x 2 cycles x active-lane fraction, from the PMC pass)."""
+# kernel kind (PtStats.kernelMs index, pathtracer_amd.PT_K_NAMES) -> the kernel it times
+KERNEL_OF = {'extend': 'k_extend / k_extend_refill', 'connect': 'k_connect', 'occluded': 'k_occluded', 'shade': 'k_shade',
+             'accumulate': 'k_accumulate', 'other': 'k_scan', 'raygen': 'k_raygen', 'raygen_extend': 'k_raygen_extend',
+             'shade_occluded': 'k_shade_occluded', 'shade_traced': 'k_shade_traced<false>', 'sample_traced': 'k_sample_traced'}
+
+
+def kernel_work(kind, st, visits, npix_launches):
+    """What one kernel kind did over the timed region: (units, records, nodes, tris, what).  units = its work items;
+    records = bytes of queue / radiance / accumulator records it must read or write in HBM whatever the caches do (a
+    lower bound: tables that stay in cache and read-modify-writes of chain radiance are left out and named in `what`);
+    nodes / tris = box tests and triangle tests of the rays it traces."""
+    S, H, Hp = st.samples, st.hits, st.hitsPrimary
+    const = st.samplesConstantSky
+    wl, wi, wo = st.raysLightInSample, st.raysIndirectInSample, st.raysOcclusionInSample
+    fl, fi, fo, fp = st.raysLightInShade, st.raysIndirectInShade, st.raysOcclusionInShade, st.raysPrimaryInShade
+    nc, tc, na, ta = visits['nodes_closest'], visits['tris_closest'], visits['nodes_any'], visits['tris_any']
+    if kind == 'sample_traced':
+        closest, anyh = fp + wl + wi, wo
+        rec = (S - const) * (4.0 + 16.0) + st.chainHitsFromSample * 32.0
+        return S, rec, closest * nc + anyh * na, closest * tc + anyh * ta, \
+            'per sample outside constant sky: 4 B sample count read + 16 B radiance record written; 32 B per hit of a chain\'s first ray'
+    if kind == 'shade_traced':
+        units = H - Hp
+        closest, anyh = (fl - wl) + (fi - wi), fo - wo
+        later = max(0, units - st.chainHitsFromSample)
+        rec = units * 32.0 + later * (32.0 + 24.0 + 24.0)
+        return units, rec, closest * nc + anyh * na, closest * tc + anyh * ta, \
+            '32 B hit record read per vertex; per hit of a later bounce 32 B record + 24 B throughput and generator written and read back; the 32 B read-modify-write of a chain\'s radiance is not counted'
+    if kind == 'accumulate':
+        rec = (S - const) * 16.0 + npix_launches * 32.0 + st.chainHitsFromSample * 16.0
+        return npix_launches, rec, 0.0, 0.0, '16 B radiance record per sample outside constant sky, 16 B per chain record that holds anything, 32 B of accumulator per pixel and launch'
+    if kind == 'raygen_extend':
+        traced = S - st.raysCulled
+        rec = (S - const) * 4.0 + (S - const - Hp) * 16.0 + Hp * 32.0
+        return traced, rec, traced * nc, traced * tc, '4 B sample count per sample outside constant sky, 16 B radiance record per miss, 32 B hit record per hit'
+    if kind == 'shade_occluded':
+        rec = Hp * (32.0 + 16.0)
+        return Hp, rec, st.raysOcclusion * na, st.raysOcclusion * ta, '32 B hit record read + 16 B radiance record written per view-ray hit (normals and materials, 64 B per hit, stay in cache)'
+    if kind == 'raygen':
+        rec = (S - const) * (4.0 + 16.0)
+        return S, rec, 0.0, 0.0, '4 B sample count read + 16 B written (queued direction or the radiance of a miss) per sample outside constant sky'
+    if kind == 'extend':
+        prim = S - st.raysCulled - fp
+        ind = st.raysIndirect - fi
+        rays = prim + ind
+        rec = prim * 16.0 + ind * 32.0 + (H - (Hp if fp else 0)) * 32.0 + max(0, prim - Hp) * 16.0
+        return rays, rec, rays * nc, rays * tc, '16 B per view ray / 32 B per indirect ray read, 32 B hit record per hit, 16 B radiance record per view-ray miss'
+    if kind == 'connect':
+        rays = st.raysLight - fl
+        return rays, rays * (48.0 + 32.0), rays * nc, rays * tc, '48 B queue entry read per ray, 32 B read-modify-write of the radiance record when the light is reached'
+    if kind == 'occluded':
+        rays = st.raysOcclusion - fo
+        ent = st.envEntries
+        return rays, ent * (64.0 + 16.0), rays * na, rays * ta, '64 B queue entry read + 16 B radiance record written per vertex with a sun or sky ray'
+    if kind == 'shade':
+        units = H - (Hp if fp else 0) - (0 if not fi else H - Hp)
+        rec = units * 32.0 + (st.raysLight - fl) * 48.0 + (st.envEntries if not fo else 0) * 64.0 + (st.raysIndirect - fi) * 32.0
+        return units, rec, 0.0, 0.0, '32 B hit record read per vertex; 48 B per light-sample ray, 64 B per sun/sky entry, 32 B per continuation ray written'
+    return None
+
+
+def ceilings(kind, st, visits, ms, launches, pmc, scene_in_lds, npix_launches):
+    """Fractions of the ceilings one kernel can be held against, none of which can exceed 1 by construction of its
+    numerator: HBM (records that must cross HBM, plus -- scene in global memory -- every node and triangle byte once per
+    launch at most), LDS (box and triangle bytes served from the scene copy in LDS), L2 (scene in global memory: records +
+    every box and triangle byte the rays read, in the layout the kernels read) and vector lane operations (issued vector
+    instructions x 2 cycles x active-lane fraction, from the counter pass of this same kernel)."""
     if not launches or ms <= 0:
         return None
-    sec = ms * 1e-3
-    fused_prim = st.raysPrimaryInShade
-    fused_ind, fused_occ, fused_light = st.raysIndirectInShade, st.raysOcclusionInShade, st.raysLightInShade   # rays the shading kernel traced itself
-    if kind == 'extend':
-        rays = st.raysPrimary - st.raysCulled - fused_prim + st.raysIndirect - fused_ind
-        stream, nodes, tris = rays * B_STREAM_CLOSEST, rays * visits['nodes_closest'], rays * visits['tris_closest']
-    elif kind == 'connect':
-        rays = st.raysLight - fused_light
-        stream, nodes, tris = rays * B_STREAM_CLOSEST, rays * visits['nodes_closest'], rays * visits['tris_closest']
-    elif kind == 'occluded':
-        rays = st.raysOcclusion - fused_occ
-        stream, nodes, tris = rays * B_STREAM_ANY, rays * visits['nodes_any'], rays * visits['tris_any']
-    elif kind == 'shade':
-        # per shaded vertex: hit record 32 B + three normals 48 B + material 16 B read; written: 48 B per light-group ray,
-        # 64 B per queued sun/sky entry, 32 B per queued continuation ray (+ 24 B of throughput and generator state from
-        # the second bounce on: not counted).  Rays traced inside the kernel move no ray record: a vertex whose sun / sky
-        # rays are traced here writes its 16 B radiance record, a continuation ray that hits writes a 32 B hit record;
-        # their box and triangle tests are served from the kernel's scene copy in LDS.
-        rays = st.hits
-        env_queued = st.envEntries if not fused_occ else 0
-        # The whole-sample kernel (view ray generated, traced and shaded in one launch) reads the 4 B sample count of a
-        # pixel per sample and no hit record for view-ray hits.
-        fused = fused_ind or fused_occ or fused_light or fused_prim
-        hits_read = st.hits - (st.hitsPrimary if fused_prim else 0)
-        stream = (hits_read * 32.0 + st.hits * 64.0 + (st.raysLight - fused_light) * 48.0 + env_queued * 64.0
-                  + (st.raysIndirect - fused_ind) * 32.0 + (st.hitsPrimary * 16.0 + (st.hits - st.hitsPrimary) * 32.0 if fused else 0.0)
-                  + (st.samples * 4.0 + (st.samples - st.hitsPrimary - st.raysCulled) * 16.0 if fused_prim else 0.0))
-        nodes = (fused_prim + fused_ind + fused_light) * visits['nodes_closest'] + fused_occ * visits['nodes_any']
-        tris = (fused_prim + fused_ind + fused_light) * visits['tris_closest'] + fused_occ * visits['tris_any']
-    else:
+    w = kernel_work(kind, st, visits, npix_launches)
+    if not w or w[0] <= 0:
         return None
-    scene_bytes = nodes * B_NODE + tris * B_TRI
-    # What must cross HBM whatever the caches do: the queue records.  The nodes and triangles of a scene in global
-    # memory are re-read by every ray and served by L2 and the Infinity Cache as far as they reach: their algorithmic
-    # bytes are held against the L2's bandwidth (they would exceed the HBM peak: on the soup 8.6 TB/s), and what
-    # really reaches HBM is the measured figure of the counter pass below.
-    hbm_bytes = stream
-    out = {'units_per_launch': round(rays / launches, 1), 'avg_launch_us': round(1e3 * ms / launches, 3),
+    units, rec, nodes, tris, what = w
+    sec = ms * 1e-3
+    canonical = nodes * B_NODE + tris * B_TRI                    # 32-byte boxes, 36-byte triangles
+    as_read = nodes * visits.get('node_bytes', B_NODE) + tris * 48.0
+    hbm_bytes = rec
+    if not scene_in_lds and canonical:
+        hbm_bytes = rec + min(as_read, float(st.sceneBytes) * launches)
+    out = {'kernel': KERNEL_OF.get(kind, kind), 'units_per_launch': round(units / launches, 1), 'avg_launch_us': round(1e3 * ms / launches, 3),
            'hbm': {'algorithmic_bytes_per_launch': round(hbm_bytes / launches, 1), 'achieved_GBps': round(hbm_bytes / sec / 1e9, 2),
-                   'frac': round(hbm_bytes / sec / 1e9 / HBM_PEAK_GBS, 5)}}
-    if scene_in_lds and scene_bytes:
-        out['lds'] = {'algorithmic_bytes_per_launch': round(scene_bytes / launches, 1), 'achieved_GBps': round(scene_bytes / sec / 1e9, 2),
-                      'frac': round(scene_bytes / sec / 1e9 / LDS_PEAK_GBS, 5)}
-    elif scene_bytes:
-        l2_bytes = stream + scene_bytes
-        out['l2'] = {'algorithmic_bytes_per_launch': round(l2_bytes / launches, 1), 'achieved_GBps': round(l2_bytes / sec / 1e9, 2),
-                     'frac': round(l2_bytes / sec / 1e9 / L2_PEAK_GBS, 5)}
+                   'frac': round(hbm_bytes / sec / 1e9 / HBM_PEAK_GBS, 5), 'counts': what +
+                   ('' if scene_in_lds or not canonical else '; + every node and triangle byte the launch touches, once')}}
+    if scene_in_lds and canonical:
+        out['lds'] = {'algorithmic_bytes_per_launch': round(canonical / launches, 1), 'achieved_GBps': round(canonical / sec / 1e9, 2),
+                      'frac': round(canonical / sec / 1e9 / LDS_PEAK_GBS, 5)}
+    elif canonical:
+        out['l2'] = {'algorithmic_bytes_per_launch': round((rec + as_read) / launches, 1), 'achieved_GBps': round((rec + as_read) / sec / 1e9, 2),
+                     'frac': round((rec + as_read) / sec / 1e9 / L2_PEAK_GBS, 5),
+                     'canonical_layout_bytes_per_launch': round((rec + canonical) / launches, 1),
+                     'canonical_layout_GBps': round((rec + canonical) / sec / 1e9, 2)}
     k = (pmc.get('kinds') or {}).get(kind)
     if k:
-        if k.get('hbm_bytes_per_launch'):
-            out['hbm']['measured_bytes_per_launch'] = k['hbm_bytes_per_launch']
-            out['hbm']['measured_frac_at_profiled_duration'] = k.get('hbm_frac')
-        if k.get('valu_lane_ops_per_launch'):
+        pu = k.get('units_per_launch')
+        if k.get('hbm_bytes_per_launch') and pu:
+            # the counter pass may have run another batch size: its bytes are carried over per work item
+            per_unit = k['hbm_bytes_per_launch'] / pu
+            out['hbm']['measured_bytes_per_launch'] = int(round(per_unit * units / launches))
+            out['hbm']['measured_frac'] = round(per_unit * units / sec / HBM_PEAK_GBS / 1e9, 5)
+            out['hbm']['wasted_traffic'] = round(per_unit * units / hbm_bytes, 3)
+            out['hbm']['counter_pass'] = {'launches': k.get('launches_profiled'), 'units_per_launch': pu,
+                                          'hbm_bytes_per_launch': k['hbm_bytes_per_launch'], 'hbm_frac_at_its_own_duration': k.get('hbm_frac')}
+        if k.get('valu_issue_util') is not None and k.get('lane_frac') is not None:
             out['valu'] = {'issue_utilisation': k['valu_issue_util'], 'active_lane_fraction': k['lane_frac'],
                            'frac': round(k['valu_issue_util'] * k['lane_frac'], 5),
                            'achieved_Glaneops': round(k['valu_issue_util'] * k['lane_frac'] * VALU_PEAK_GLANEOPS, 1)}
@@ -204,15 +253,24 @@ def measure(P, torch, dist, multigpu, name, args, rank, world, local_rank, rehea
         torch.cuda.synchronize()
 
     # ---- traversal-cost pass (un-timed): mean box / triangle tests per ray of each kind, 1 spp; the first render after
-    # set_camera also builds the view-ray masks on the host, whose cost is reported ----
-    pt.set_config(flags=P.PT_FLAG_COUNT_VISITS | bvh_flag)
-    pt.reset_stats()
-    pt.render_frame(1); pt.synchronize()
-    cst = pt.stats()
-    n_closest = max(1, cst.raysPrimary - cst.raysCulled + cst.raysLight + cst.raysIndirect)
-    n_any = max(1, cst.raysOcclusion)
-    visits = dict(nodes_closest=cst.nodesClosest / n_closest, tris_closest=cst.trisClosest / n_closest,
-                  nodes_any=cst.nodesAny / n_any, tris_any=cst.trisAny / n_any)
+    # set_camera also builds the view-ray masks on the GPU, whose cost is reported.  --no-visits (the counter passes of
+    # scripts/profile_workload.sh) leaves it out, so that every launch the profiler sees belongs to the timed region ----
+    if args.no_visits:
+        pt.render(0, 64, 1); pt.synchronize()              # builds the masks
+        cst = pt.stats()
+        visits = dict(nodes_closest=0.0, tris_closest=0.0, nodes_any=0.0, tris_any=0.0)
+        pt.clear_pixels()
+    else:
+        pt.set_config(flags=P.PT_FLAG_COUNT_VISITS | bvh_flag)
+        pt.reset_stats()
+        pt.render_frame(1); pt.synchronize()
+        cst = pt.stats()
+        n_closest = max(1, cst.raysPrimary - cst.raysCulled + cst.raysLight + cst.raysIndirect)
+        n_any = max(1, cst.raysOcclusion)
+        visits = dict(nodes_closest=cst.nodesClosest / n_closest, tris_closest=cst.trisClosest / n_closest,
+                      nodes_any=cst.nodesAny / n_any, tris_any=cst.trisAny / n_any)
+    # bytes per box test as the kernels read them: 32 B in the LDS copy; from global memory, the node format's
+    visits['node_bytes'] = 32.0 if cst.sceneInLds else cst.sceneBytes and (cst.sceneBytes - 48.0 * tri_slots(cst)) / max(1, cst.numNodes)
 
     # ---- warm-up, then the timed region with every kernel launch bracketed by HIP events on the launch stream ----
     pt.set_config(flags=P.PT_FLAG_TIME_KERNELS | bvh_flag)
@@ -243,36 +301,47 @@ def measure(P, torch, dist, multigpu, name, args, rank, world, local_rank, rehea
         return None
 
     pmc, pmc_src = profile_json(name)
-    if args.batch_slots or args.max_leaf or args.spp:
+    if args.batch_slots or args.max_leaf:
         pmc, pmc_src = {}, None                                  # the committed passes ran the default configuration
     kern, ceil = {}, {}
     for i, kname in enumerate(P.PT_K_NAMES):
         if st.kernelLaunches[i]:
             kern[kname] = dict(launches=int(st.kernelLaunches[i]), total_ms=round(st.kernelMs[i], 4),
                                avg_us=round(1e3 * st.kernelMs[i] / st.kernelLaunches[i], 3))
-            c = ceilings(kname, st, visits, st.kernelMs[i], st.kernelLaunches[i], pmc, bool(st.sceneInLds))
+            c = ceilings(kname, st, visits, st.kernelMs[i], st.kernelLaunches[i], pmc, bool(st.sceneInLds),
+                         float(W * H) * st.kernelLaunches[i] / (world if args.split == 'bands' else 1))
             if c:
                 ceil[kname] = c
-    # the dominant kernel: the kind with the largest summed time; its binding ceiling heads the roofline object
+    # the dominant kernel: the one with the largest summed time; its binding ceiling heads the roofline object
     dom = max(ceil, key=lambda k: kern[k]['total_ms'])
     d = ceil[dom]
     fr = {k: d[k]['frac'] for k in ('hbm', 'lds', 'l2', 'valu') if k in d}
+    if 'measured_frac' in d['hbm']:
+        fr['hbm'] = max(fr['hbm'], d['hbm']['measured_frac'])        # what the counters saw cross HBM bounds the kernel no less
     bound = max(fr, key=fr.get)
     if bound == 'valu':
         achieved, peak, unit = d['valu']['achieved_Glaneops'], VALU_PEAK_GLANEOPS, 'Glaneop/s'
     else:
-        achieved, peak, unit = d[bound]['achieved_GBps'], {'hbm': HBM_PEAK_GBS, 'lds': LDS_PEAK_GBS, 'l2': L2_PEAK_GBS}[bound], 'GB/s'
+        achieved, peak, unit = round(fr[bound] * {'hbm': HBM_PEAK_GBS, 'lds': LDS_PEAK_GBS, 'l2': L2_PEAK_GBS}[bound], 2), \
+            {'hbm': HBM_PEAK_GBS, 'lds': LDS_PEAK_GBS, 'l2': L2_PEAK_GBS}[bound], 'GB/s'
+    measured = d['hbm'].get('measured_bytes_per_launch')
     roofline = dict(bound=bound, achieved=achieved, peak=peak, unit=unit, frac=fr[bound],
-                    traffic=d['hbm'].get('measured_bytes_per_launch'), kernel=dom, launches=kern[dom]['launches'],
+                    traffic=measured, kernel=d['kernel'], kind=dom, launches=kern[dom]['launches'],
                     avg_launch_us=kern[dom]['avg_us'],
-                    traffic_source=(pmc_src + ' (rocprofv3 --pmc passes of the same command, read from the committed file: the counters '
-                                    'need profiler processes of their own)') if pmc_src and d['hbm'].get('measured_bytes_per_launch') else None,
-                    definition='frac = achieved / peak of the binding ceiling of the dominant kernel; hbm: algorithmic bytes that must '
-                               'cross HBM (queue records) / launch time / 8 TB/s; lds: node + triangle bytes served from the scene copy in LDS / 150 TB/s; '
-                               'l2 (scene in global memory): records + node + triangle bytes / 34.5 TB/s; '
-                               'valu: vector instructions x 2 cycles / SIMD cycles x active-lane fraction (PMC)',
+                    algorithmic_hbm_bytes_per_launch=d['hbm']['algorithmic_bytes_per_launch'],
+                    wasted_traffic=d['hbm'].get('wasted_traffic'),
+                    hbm_frac_algorithmic=d['hbm']['frac'], hbm_frac_measured=d['hbm'].get('measured_frac'),
+                    traffic_source=(pmc_src + ' (rocprofv3 --pmc passes of this workload without the visit-counting pass, one counter block per '
+                                    'profiler process, read from the committed file; carried over per work item of this kernel)') if pmc_src and measured else None,
+                    definition='frac = achieved / peak of the binding ceiling of the dominant kernel (the one with the largest summed time); '
+                               'hbm: bytes that must cross HBM (records; scene in global memory: + every node and triangle byte once per launch), or the '
+                               'HBM bytes the counters measured when those are more, / launch time / 8 TB/s; lds: box + triangle bytes served from the '
+                               'scene copy in LDS / 150 TB/s; l2 (scene in global memory): records + box + triangle bytes as read / 34.5 TB/s; '
+                               'valu: vector instructions x 2 cycles / SIMD cycles x active-lane fraction (counter pass of this kernel); '
+                               'wasted_traffic = measured / algorithmic HBM bytes',
                     bytes_per_ray=dict(closest=round(B_STREAM_CLOSEST + visits['nodes_closest'] * B_NODE + visits['tris_closest'] * B_TRI, 2),
-                                       any=round(B_STREAM_ANY + visits['nodes_any'] * B_NODE + visits['tris_any'] * B_TRI, 2)),
+                                       any=round(B_STREAM_ANY + visits['nodes_any'] * B_NODE + visits['tris_any'] * B_TRI, 2),
+                                       layout='canonical: 48 / 36 B of records, 32 B per box test, 36 B per triangle test'),
                     visits_per_ray={k: round(v, 4) for k, v in visits.items()}, ceilings=ceil,
                     scene='nodes + triangles staged in LDS by the traversal kernels' if st.sceneInLds else 'traversed from HBM / L2')
 
@@ -318,6 +387,7 @@ def main():
     ap.add_argument('--max-leaf', type=int, default=0)
     ap.add_argument('--soup-tris', type=int, default=10_000_000, help='triangles of the synthetic soup workload')
     ap.add_argument('--bvh', default='auto', choices=['auto', 'gpu', 'host'], help='where the BVH is built (auto: GPU from 1 M triangles)')
+    ap.add_argument('--no-visits', action='store_true', help='skip the un-timed visit-counting pass (counter passes under the profiler)')
     ap.add_argument('--only', action='store_true', help='measure only --workload (no other_workloads, no pass latency)')
     args = ap.parse_args()
 

@@ -71,7 +71,8 @@ typedef struct PtConfig {
 #define PT_FLAG_HOST_BVH 32u      /* always build the BVH on the host                                     */
 #define PT_FLAG_NO_GRAPH 64u      /* never replay a small batch from a HIP graph (default: a ptgpu_render / _bands call that is
                                      one batch of at most 4 Mi samples is captured the second time it is issued with the
-                                     same arguments, scene, camera and configuration, and replayed from then on)     */
+                                     same arguments, scene, camera and configuration, and replayed from then on -- on the
+                                     stream the handle made itself; after ptgpu_set_stream every call launches its kernels) */
 #define PT_FLAG_NO_FUSE 128u      /* one launch per stage of the wavefront (raygen, extend, shade, connect, occluded), queues
                                      in between.  Default: stages are merged where that saves queue traffic and
                                      launches with the same rays and results -- scenes whose nodes, triangles and
@@ -93,8 +94,14 @@ typedef struct PtConfig {
 typedef struct PtMaterial { float emissive; float color[3]; } PtMaterial;        /* rendering.d:33-37 */
 typedef struct PtPixel { float color[3]; float n; float sum[3]; } PtPixel;        /* rendering.d:24-30 */
 
-/* Kernel kinds reported by ptgpu_get_stats */
-enum { PT_K_EXTEND = 0, PT_K_CONNECT = 1, PT_K_OCCLUDED = 2, PT_K_SHADE = 3, PT_K_ACCUM = 4, PT_K_OTHER = 5, PT_K_COUNT = 6 };
+/* Kernel kinds reported by ptgpu_get_stats: one per kernel of the render path.  OTHER = the queue scans. */
+enum { PT_K_EXTEND = 0, PT_K_CONNECT = 1, PT_K_OCCLUDED = 2, PT_K_SHADE = 3, PT_K_ACCUM = 4, PT_K_OTHER = 5,
+       PT_K_RAYGEN = 6,          /* view rays generated into a queue                                                 */
+       PT_K_RAYGEN_EXTEND = 7,   /* view rays generated by the kernel that traces them (scenes in LDS)              */
+       PT_K_SHADE_OCCLUDED = 8,  /* the sun / sky traversal kernel that shades the view-ray hits it reads            */
+       PT_K_SHADE_TRACED = 9,    /* shading of chain hits that traces the rays it spawns, all bounce rounds          */
+       PT_K_SAMPLE_TRACED = 10,  /* a whole sample per lane: raygen, view ray, shading and the rays it spawns        */
+       PT_K_COUNT = 11 };
 
 typedef struct PtStats {
   uint64_t raysPrimary;      /* Scene.trace calls from computeL             (rendering.d:471)            */
@@ -113,6 +120,13 @@ typedef struct PtStats {
   uint64_t raysLightInShade;     /* (or the whole-sample kernel) traced itself                                          */
   uint64_t raysIndirectInShade;  /* instead of queueing them for the traversal kernels (small scenes, see              */
   uint64_t raysOcclusionInShade; /* PT_FLAG_NO_FUSE)                                                                   */
+  uint64_t raysLightInSample;    /* of the three above: rays traced by the whole-sample kernel (PT_K_SAMPLE_TRACED); the rest  */
+  uint64_t raysIndirectInSample; /* were traced by the shading of chain hits (PT_K_SHADE_TRACED, or PT_K_SHADE with             */
+  uint64_t raysOcclusionInSample;/* PT_FLAG_QUEUED_VIEW_RAYS)                                                                   */
+  uint64_t chainHitsFromSample;  /* hits of the chains' first rays that the whole-sample kernel appended for PT_K_SHADE_TRACED  */
+  uint64_t samplesConstantSky;   /* of raysCulled: samples of pixels whose every sample is the sky constant (nothing is read    */
+                                 /* or written for them until accumulate adds the constant)                                     */
+  uint64_t sceneBytes;           /* nodes + triangles as the traversal kernels read them (LDS copy or global memory)            */
   double kernelMs[PT_K_COUNT];          /* with PT_FLAG_TIME_KERNELS: summed event time per kernel kind   */
   uint64_t kernelLaunches[PT_K_COUNT];
   double renderMs;           /* event time first kernel -> last kernel of all ptgpu_render calls          */
@@ -179,10 +193,15 @@ int ptgpu_synchronize(PtHandle* h);
  * counters) lives in a static device array of PT_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds for
  * the life of the process, and the call makes no hipMalloc / hipFree, creates no event and builds nothing on the
  * host.  The whole window is ONE batch: pixelCount * spp must fit the array for the handle's scene and configuration
- * (mode 0: 655360 samples for a scene without light groups, 458752 with one; mode 1 with five chains: 65536); a larger request fails with PT_E_INVALID and a message
+ * (a scene whose samples are one launch each, i.e. up to 24 KB of nodes, triangles and shading tables, keeps no ray
+ * queues: 1769472 samples in mode 0, 131072 in mode 1 with five chains; other scenes, mode 0: 655360 samples without
+ * light groups, 458752 with one; mode 1 with five chains: 65536); a larger request fails with PT_E_INVALID and a message
  * that states the limit.  The view-ray masks are used when an earlier ptgpu_render built them for the current
  * camera, otherwise the rays are culled by the scene's bounding box (same image).  All calls on one GPU share the
- * array: calls that overlap in time on one GPU (two streams, two handles) race; serialise them. */
+ * array.  The library puts them in order: a call's kernels start behind the last kernel of the previous call on that
+ * GPU, whatever handle, stream or host thread issued it (a stream wait on an event, no host wait), so calls that would
+ * overlap run one after the other instead of racing.  Under a stream capture no such wait is recorded: the order is
+ * the capturing caller's to give. */
 #define PT_NOALLOC_SCRATCH_BYTES (96u << 20)
 int ptgpu_render_noalloc(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount, uint32_t spp);
 
@@ -230,7 +249,7 @@ int ptgpu_view_rays(PtHandle* h, uint32_t pixelOffset, uint32_t count, float* ra
 int ptgpu_rng_stream(PtHandle* h, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n, uint32_t* out);
 /* Parity probe: angleToDirection(phi, psi, normal) (rendering.d:316-330) as the shading kernels evaluate it, for n rows
  * of 5 floats (phi, psi, normal.xyz); a row with a zero normal gets angleToLocalDirection(phi, psi) (rendering.d:309-314).
- * out3 = n x 3.  cosf / sinf are evaluated in binary64 in one fixed order and rounded once (pt_math.h: sincosFixed). */
+ * out3 = n x 3.  cosf / sinf are one fixed sequence of binary32 operations (pt_math.h: sincosFixed). */
 int ptgpu_angle_directions(PtHandle* h, const float* in5, uint32_t n, float* out3);
 /* Parity probe (no reference counterpart): the masks the view rays of getViewRay (rendering.d:278-285) are culled
  * with for the current scene and camera, ceil(width*height/32) words each, either may be NULL.  Bit p of covered is

@@ -55,6 +55,11 @@ static __device__ __align__(256) unsigned char scratch[PT_NOALLOC_BYTES];
 constexpr int PT_MAX_DEVICES = 64;
 void* g_scratchPtr[PT_MAX_DEVICES] = {};
 std::mutex g_scratchMu;
+// All calls on one GPU share that GPU's array.  They are put in order instead of racing: a call enqueues its work
+// under the device's mutex, first making its stream wait for the event the previous call on that device recorded
+// behind its last kernel, and records the event again behind its own.  Neither the wait nor the record allocates.
+hipEvent_t g_scratchDone[PT_MAX_DEVICES] = {};
+std::mutex g_scratchCall[PT_MAX_DEVICES];
 
 // Address of `scratch` on the current device (which must be `device`); looked up once per device.
 void* scratchOnDevice(int device) {
@@ -64,6 +69,10 @@ void* scratchOnDevice(int device) {
     void* p = nullptr;
     hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
     if (e != hipSuccess || !p) fail(PT_E_DEVICE, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+    hipEvent_t ev = nullptr;
+    e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) fail(PT_E_DEVICE, std::string("hipEventCreateWithFlags: ") + hipGetErrorString(e));
+    g_scratchDone[device] = ev;
     g_scratchPtr[device] = p;
   }
   return g_scratchPtr[device];
@@ -338,6 +347,7 @@ void uploadScene(PtHandle* h) {
   d.numLightGroups = (uint32_t)lt.numGroups(); d.numMats = (uint32_t)fs.mats.size(); d.numLightTris = (uint32_t)lt.tris.size();
   for (int k = 0; k < 3; k++) { h->box.mn[k] = bvh.nodes[k]; h->box.mx[k] = bvh.nodes[4 + k]; }   // node 0 = root
   h->haveScene = true; h->sceneGeneration++;
+  h->st.sceneBytes = (uint64_t)bvh.numNodes * (d.ldsBytes ? 32 : 16) + (uint64_t)NT * 48;
   h->st.numTriangles = T; h->st.numNodes = bvh.numNodes; h->st.bvhDepth = bvh.depth;
   h->st.numLightGroups = d.numLightGroups; h->st.sceneInLds = d.ldsBytes ? 1 : 0;
 }
@@ -508,7 +518,7 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
       Timed t(h, PT_K_EXTEND); launchExtend(lc, h->dsc, dc, pm, h->acc, wf, true); t.done();
       scan((size_t)s * perStage, 1);
     }
-    { Timed t(h, PT_K_SHADE); launchShade(lc, h->dsc, dc, pm, h->acc, wf, primary); t.done(); }
+    { Timed t(h, primary ? PT_K_SHADE : PT_K_SHADE_TRACED); launchShade(lc, h->dsc, dc, pm, h->acc, wf, primary); t.done(); }
     // (no scan of what it appended: the traced shading of chain hits takes its queue segment by segment)
   };
   uint32_t nslots = pm.npix * pm.k;
@@ -519,7 +529,7 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
     bind(1);
     wf.hitOutA = pairA[0]; wf.hitOutB = pairB[0];
     if (dc.mode == 1) wf.rayOut = ws.hostMetas[(size_t)2 * perStage];
-    { Timed t(h, PT_K_SHADE); launchSampleTraced(lc, h->box, ws.masks, h->dsc, dc, pm, h->acc, nslots, wf); t.done(); }
+    { Timed t(h, PT_K_SAMPLE_TRACED); launchSampleTraced(lc, h->box, ws.masks, h->dsc, dc, pm, h->acc, nslots, wf); t.done(); }
     if (dc.mode == 1) fusedStage(2, false);                // one launch goes through all bounce rounds
     { Timed t(h, PT_K_ACCUM); launchAccumulate(lc, ws.masks, dc, pm, h->acc, wf, h->dsc); t.done(); }
     HIPCHECK(hipGetLastError());
@@ -530,10 +540,10 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
   const bool rayExt = !wf.fuse && h->dsc.ldsBytes && !lc.countVisits && !(h->cfg.flags & PT_FLAG_NO_FUSE);
   if (rayExt) {
     bind(1);
-    { Timed t(h, PT_K_EXTEND); launchRaygenExtend(lc, h->box, ws.masks, h->dsc, dc, pm, h->acc, nslots, wf); t.done(); }
+    { Timed t(h, PT_K_RAYGEN_EXTEND); launchRaygenExtend(lc, h->box, ws.masks, h->dsc, dc, pm, h->acc, nslots, wf); t.done(); }
     scan((size_t)perStage, 1);
     if (dc.mode == 0 && envDirect(dc, h->dsc, true)) {
-      { Timed t(h, PT_K_OCCLUDED); launchShadeOccluded(lc, h->dsc, dc, pm, h->acc, wf); t.done(); }
+      { Timed t(h, PT_K_SHADE_OCCLUDED); launchShadeOccluded(lc, h->dsc, dc, pm, h->acc, wf); t.done(); }
     } else {
       { Timed t(h, PT_K_SHADE); launchShade(lc, h->dsc, dc, pm, h->acc, wf, true); t.done(); }
       scan((size_t)perStage + 1, 1 + kinds);
@@ -546,7 +556,7 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
     return;
   }
   wf.rayOut = ws.hostMetas[1];
-  { Timed t(h, PT_K_OTHER); launchRaygen(lc, h->box, ws.masks, dc, pm, h->acc, nslots, wf); t.done(); }
+  { Timed t(h, PT_K_RAYGEN); launchRaygen(lc, h->box, ws.masks, dc, pm, h->acc, nslots, wf); t.done(); }
   scan(1, 1);
   if (wf.fuse) {
     fusedStage(1, true);
@@ -556,7 +566,7 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
     bind(1);
     { Timed t(h, PT_K_EXTEND); launchExtend(lc, h->dsc, dc, pm, h->acc, wf, true); t.done(); }
     scan((size_t)perStage, 1);
-    { Timed t(h, PT_K_OCCLUDED); launchShadeOccluded(lc, h->dsc, dc, pm, h->acc, wf); t.done(); }
+    { Timed t(h, PT_K_SHADE_OCCLUDED); launchShadeOccluded(lc, h->dsc, dc, pm, h->acc, wf); t.done(); }
   } else {
     stage(1, true);
     if (dc.mode == 1)      // depth 0..maxDepth can still spawn a ray (the check is depth > maxDepth, rendering.d:380)
@@ -638,10 +648,16 @@ void renderPixels(PtHandle* h, PixMap base, uint64_t totalPix, uint32_t spp, con
       HIPCHECK(hipGraphLaunch(h->graphExec, h->stream));
       countBatch(); span.done(); return;
     }
-    if (key == h->graphSeen) {                 // second call of this shape: capture it
+    // Captured only on the stream the handle made itself: a caller's stream may be the legacy null stream, which cannot
+    // be captured, or be under a capture of the caller's own.  When the capture cannot begin, the batch runs as usual.
+    bool capturing = false;
+    if (key == h->graphSeen && h->ownStream) {     // second call of this shape: capture it
       if (h->graphExec) { (void)hipGraphExecDestroy(h->graphExec); h->graphExec = nullptr; h->graphKey.clear(); }
+      if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) capturing = true;
+      else { (void)hipGetLastError(); h->graphSeen.clear(); }
+    }
+    if (capturing) {
       hipGraph_t graph = nullptr;
-      HIPCHECK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
       try {
         // chain radiance records are told apart by the batch tag, which is fixed in a captured launch: clear the part
         // of them this batch uses, so that a replay never meets its own tag from the replay before
@@ -651,14 +667,15 @@ void renderPixels(PtHandle* h, PixMap base, uint64_t totalPix, uint32_t spp, con
         renderBatch(h, dc, lc, pm, ws);
         h->noEvents = false;
       } catch (...) {
-        h->noEvents = false;
+        h->noEvents = false; h->graphSeen.clear();
         (void)hipStreamEndCapture(h->stream, &graph); if (graph) (void)hipGraphDestroy(graph);
         throw;
       }
-      HIPCHECK(hipStreamEndCapture(h->stream, &graph));
+      hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+      if (ce != hipSuccess) { h->graphSeen.clear(); fail(PT_E_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce)); }
       hipError_t ge = hipGraphInstantiate(&h->graphExec, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
-      if (ge != hipSuccess) { h->graphExec = nullptr; fail(PT_E_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(ge)); }
+      if (ge != hipSuccess) { h->graphExec = nullptr; h->graphSeen.clear(); fail(PT_E_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(ge)); }
       h->graphKey = key;
       HIPCHECK(hipGraphLaunch(h->graphExec, h->stream));
       span.done(); return;                     // (renderBatch has counted the batch while it was captured)
@@ -725,7 +742,10 @@ int ptgpu_create(const PtConfig* cfg, PtHandle** out) {
     h->scratchDev = (unsigned char*)scratchOnDevice(c.device);
     h->metasNoAlloc.resize((size_t)(64 + 4) * (2 + PT_MAX_KINDS));        // maxDepth <= 64 (validateConfig)
   });
-  if (rc != PT_OK) { delete h; return rc; }
+  if (rc != PT_OK) {                        // give back the streams and events made so far (ptgpu_destroy keeps g_err's message apart)
+    if (h) { const std::string why = g_err; (void)ptgpu_destroy(h); g_err = why; }
+    return rc;
+  }
   *out = h; return PT_OK;
 }
 
@@ -752,7 +772,7 @@ int ptgpu_set_config(PtHandle* h, const PtConfig* cfg) {
     if (c.device != h->cfg.device || c.width != h->cfg.width || c.height != h->cfg.height || c.batchSlots != h->cfg.batchSlots)
       fail(PT_E_INVALID, "device, width, height and batchSlots are fixed at ptgpu_create");
     bool rebuild = c.maxLeafTris != h->cfg.maxLeafTris ||
-                   ((c.flags ^ h->cfg.flags) & (PT_FLAG_NO_LDS_SCENE | PT_FLAG_GPU_BVH | PT_FLAG_HOST_BVH));
+                   ((c.flags ^ h->cfg.flags) & (PT_FLAG_NO_LDS_SCENE | PT_FLAG_GPU_BVH | PT_FLAG_HOST_BVH | PT_FLAG_NO_TREELETS));
     if ((c.flags ^ h->cfg.flags) & PT_FLAG_NO_COVERAGE_MASK) h->maskDirty = true;
     h->cfg = c;
     if (rebuild && h->haveScene) { if (h->cfg.device >= 0) useDevice(h); uploadScene(h); }
@@ -864,7 +884,8 @@ int ptgpu_render(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount, uint32_
 namespace {
 struct NoAllocLayout {
   size_t slotQ, hitA, hitB, rayO, rayD, Lacc, thr, rng, shO, shD, shW, shX, words, desc, total;
-  uint32_t capSlots, capQueue, capHit, lanes, kinds, rounds;
+  uint32_t capSlots, capQueue, capHit, lanes, kinds, rounds, rayCap;
+  bool lean;
 };
 constexpr uint32_t PT_NOALLOC_GROUPS = 128;      // traversal workgroups per launch: bounds the hit queue's slack
 
@@ -873,6 +894,9 @@ NoAllocLayout layoutNoAlloc(const PtHandle* h, uint32_t capSlots) {
   NoAllocLayout L{};
   const uint32_t NI = c.mode == 1 ? c.numIndirect : 0;
   L.capSlots = capSlots; L.lanes = 1 + NI; L.kinds = numKinds(h); L.rounds = c.mode == 1 ? c.maxDepth + 4 : 2;
+  // as ensureWavefront: a scene whose batches are whole-sample launches keeps no view-ray queue and no shadow queues,
+  // and its ray arrays are as large as the hit arrays (the two pairs alternate between bounce rounds)
+  L.lean = sceneFusable(h) && !(c.flags & PT_FLAG_QUEUED_VIEW_RAYS);
   const uint64_t capQueue = (uint64_t)capSlots * std::max(1u, NI);
   uint64_t capHit = capQueue + (uint64_t)PT_NOALLOC_GROUPS * PT_HIT_SLACK;
   capHit = (capHit + PT_SEGS - 1) / PT_SEGS * PT_SEGS;
@@ -880,19 +904,32 @@ NoAllocLayout layoutNoAlloc(const PtHandle* h, uint32_t capSlots) {
   L.capQueue = (uint32_t)capQueue; L.capHit = (uint32_t)capHit;
   size_t at = 0;
   auto piece = [&](uint64_t bytes) { size_t o = at; at += (size_t)((bytes + 255) / 256 * 256); return o; };
-  L.slotQ = piece((uint64_t)capSlots * 16);
+  L.slotQ = piece(L.lean ? 16 : (uint64_t)capSlots * 16);
   L.hitA = piece(capHit * 16); L.hitB = piece(capHit * 16);
-  L.rayO = piece(NI ? capQueue * 16 : 16); L.rayD = piece(NI ? capQueue * 16 : 16);
+  const uint64_t rayEntries = !NI ? 1 : L.lean ? capHit : capQueue;
+  L.rayCap = NI && L.lean ? (uint32_t)capHit : 0u;
+  L.rayO = piece(rayEntries * 16); L.rayD = piece(rayEntries * 16);
   L.Lacc = piece((uint64_t)L.lanes * capSlots * 16);
   L.thr = piece(NI ? (uint64_t)L.lanes * capSlots * 16 : 16);
   L.rng = piece(NI ? (uint64_t)L.lanes * capSlots * 8 : 16);
-  L.shO = piece((uint64_t)L.kinds * capQueue * 16); L.shD = piece((uint64_t)L.kinds * capQueue * 16);
-  L.shW = piece((uint64_t)L.kinds * capQueue * 16); L.shX = piece(capQueue * 16);
+  const uint64_t sh = L.lean ? 16 : (uint64_t)L.kinds * capQueue * 16;
+  L.shO = piece(sh); L.shD = piece(sh); L.shW = piece(sh); L.shX = piece(L.lean ? 16 : capQueue * 16);
   const uint64_t nMetas = (uint64_t)L.rounds * (2 + PT_MAX_KINDS);
   L.words = piece(nMetas * PT_QMETA_WORDS * 4 + (PT_TASK_COUNTERS + PT_POOL_WORDS) * 4);
   L.desc = piece(nMetas * sizeof(QMeta));
   L.total = at;
   return L;
+}
+
+// The largest batch (a multiple of 64 * PT_SEGS slots) whose layout fits the array; the layout grows with the batch.
+uint64_t maxNoAllocSlots(const PtHandle* h) {
+  const uint64_t gran = 64ull * PT_SEGS;
+  uint64_t lo = 0, hi = 0x40000000ull / gran + 1;          // fits(lo * gran) (0: nothing), !fits(hi * gran)
+  while (hi - lo > 1) {
+    const uint64_t mid = (lo + hi) / 2;
+    if (layoutNoAlloc(h, (uint32_t)(mid * gran)).total <= PT_NOALLOC_BYTES) lo = mid; else hi = mid;
+  }
+  return lo * gran;
 }
 }  // namespace
 
@@ -906,9 +943,7 @@ int ptgpu_render_noalloc(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount,
     if (pixelCount == 0 || spp == 0) return;
     const uint64_t gran = 64ull * PT_SEGS;
     const uint64_t nslots = (uint64_t)pixelCount * spp;
-    // the largest batch the scratch array holds for this scene and configuration
-    uint64_t maxSlots = 0;
-    for (uint64_t s = gran; s <= 0x40000000ull && layoutNoAlloc(h, (uint32_t)s).total <= PT_NOALLOC_BYTES; s += gran) maxSlots = s;
+    const uint64_t maxSlots = maxNoAllocSlots(h);          // what the scratch array holds for this scene and configuration
     if (nslots > maxSlots)
       fail(PT_E_INVALID, "ptgpu_render_noalloc: pixelCount * spp = " + std::to_string(nslots) + " exceeds the " +
                              std::to_string(maxSlots) + " samples per call that the " + std::to_string(PT_NOALLOC_BYTES >> 20) +
@@ -923,7 +958,7 @@ int ptgpu_render_noalloc(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount,
     w.thr = (float4*)(base + L.thr); w.rng = (uint2*)(base + L.rng);
     w.shO = (float4*)(base + L.shO); w.shD = (float4*)(base + L.shD); w.shW = (float4*)(base + L.shW); w.shX = (float4*)(base + L.shX);
     w.stats = h->bStats.as<unsigned long long>();
-    w.capSlots = L.capSlots; w.capQueue = L.capQueue; w.capHit = L.capHit; w.lanes = L.lanes;
+    w.capSlots = L.capSlots; w.capQueue = L.capQueue; w.capHit = L.capHit; w.lanes = L.lanes; w.rayCap = L.rayCap;
     uint32_t* words = (uint32_t*)(base + L.words);
     const size_t nMetas = (size_t)L.rounds * (2 + PT_MAX_KINDS);
     for (size_t m = 0; m < nMetas; m++) {
@@ -936,6 +971,14 @@ int ptgpu_render_noalloc(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount,
     // masks built for the current scene and camera are used; none is built here (that would allocate): the view rays
     // are then culled by the scene's bounding box, which gives the same image
     ws.masks = (!h->maskDirty && h->maskUsable) ? h->masks() : ViewMasks{nullptr, nullptr};
+    // one call at a time per GPU works on the array: this one starts behind the last kernel of the previous one (any
+    // handle, any stream of this device) and the next one behind this one's.  Under a stream capture the order is the
+    // capturing caller's to give.
+    std::lock_guard<std::mutex> turn(g_scratchCall[h->cfg.device]);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    const bool ordered = cap == hipStreamCaptureStatusNone;
+    if (ordered) HIPCHECK(hipStreamWaitEvent(h->stream, g_scratchDone[h->cfg.device], 0));
     // the array keeps the last call's contents (of this or any other handle on the device): counters start at zero
     HIPCHECK(hipMemsetAsync(words, 0, nMetas * PT_QMETA_WORDS * 4 + (PT_TASK_COUNTERS + PT_POOL_WORDS) * 4, h->stream));
     // ... and so do the chain lanes' radiance records: whatever another call's layout left there must not be taken
@@ -949,6 +992,7 @@ int ptgpu_render_noalloc(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount,
     h->noEvents = true;
     try { renderPixels(h, pm, pixelCount, spp, &ws, PT_NOALLOC_GROUPS); } catch (...) { h->noEvents = false; throw; }
     h->noEvents = false;
+    if (ordered) HIPCHECK(hipEventRecord(g_scratchDone[h->cfg.device], h->stream));
   });
 }
 
@@ -1283,6 +1327,8 @@ int ptgpu_get_stats(PtHandle* h, PtStats* out) {
     h->st.nodesAny = s[STAT_NODES_ANY]; h->st.trisAny = s[STAT_TRIS_ANY]; h->st.raysCulled = s[STAT_RAYS_CULLED];
     h->st.hits = s[STAT_HITS]; h->st.envEntries = s[STAT_ENV_ENTRIES];
     h->st.hitsPrimary = s[STAT_HITS_PRIMARY]; h->st.raysPrimaryInShade = s[STAT_FUSED_PRIMARY]; h->st.raysLightInShade = s[STAT_FUSED_LIGHT]; h->st.raysIndirectInShade = s[STAT_FUSED_INDIRECT]; h->st.raysOcclusionInShade = s[STAT_FUSED_OCCL];
+    h->st.raysLightInSample = s[STAT_WHOLE_LIGHT]; h->st.raysIndirectInSample = s[STAT_WHOLE_INDIRECT]; h->st.raysOcclusionInSample = s[STAT_WHOLE_OCCL];
+    h->st.chainHitsFromSample = s[STAT_WHOLE_CHAIN_HITS]; h->st.samplesConstantSky = s[STAT_CONSTANT_SKY];
     *out = h->st;
   });
 }
@@ -1298,6 +1344,7 @@ int ptgpu_reset_stats(PtHandle* h) {
     h->st.numTriangles = keep.numTriangles; h->st.numNodes = keep.numNodes; h->st.bvhDepth = keep.bvhDepth;
     h->st.numLightGroups = keep.numLightGroups; h->st.sceneInLds = keep.sceneInLds;
     h->st.bvhOnGpu = keep.bvhOnGpu; h->st.bvhBuildSeconds = keep.bvhBuildSeconds; h->st.maskBuildMs = keep.maskBuildMs;
+    h->st.sceneBytes = keep.sceneBytes;
     h->eventOverflow = false;
   });
 }

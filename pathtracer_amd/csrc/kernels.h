@@ -169,9 +169,12 @@ constexpr uint32_t PT_FUSE_LDS_BYTES = 24 * 1024;
 
 enum { STAT_RAYS_LIGHT = 0, STAT_RAYS_INDIRECT, STAT_RAYS_OCCL, STAT_NODES_CLOSEST, STAT_TRIS_CLOSEST,
        STAT_NODES_ANY, STAT_TRIS_ANY, STAT_RAYS_CULLED, STAT_HITS, STAT_ENV_ENTRIES, STAT_FUSED_INDIRECT, STAT_FUSED_OCCL, STAT_HITS_PRIMARY, STAT_FUSED_LIGHT, STAT_FUSED_PRIMARY,
+       STAT_WHOLE_LIGHT, STAT_WHOLE_INDIRECT, STAT_WHOLE_OCCL,      // of the FUSED ones: traced by the whole-sample kernel
+       STAT_WHOLE_CHAIN_HITS,                                        // hits it appended for the shading of chain hits
+       STAT_CONSTANT_SKY,                                            // of RAYS_CULLED: samples of constant-sky pixels
        STAT_COUNT };
-constexpr int PT_STAT_REPLICAS = 64, PT_STAT_STRIDE = 16;   // copies of the counters, 128 B apart (kernels.hip: statAdd)
-static_assert(STAT_COUNT <= PT_STAT_STRIDE, "a copy of the counters is one 128-byte line");
+constexpr int PT_STAT_REPLICAS = 64, PT_STAT_STRIDE = 32;   // copies of the counters, 256 B apart (kernels.hip: statAdd)
+static_assert(STAT_COUNT <= PT_STAT_STRIDE, "a copy of the counters is two 128-byte lines of its own");
 
 // Workgroups of a traversal kernel per CU when the scene copy in LDS takes `bytes` (0: it does not fit at all).
 inline uint32_t ldsWorkgroupsPerCU(uint64_t bytes) {

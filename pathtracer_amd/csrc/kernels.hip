@@ -576,7 +576,7 @@ __global__ void __launch_bounds__(PT_RAYGEN_THREADS) k_raygen(SceneBox box, View
   if (threadIdx.x == 0) sCnt = 0;
   __syncthreads();
   uint32_t T = blockIdx.x, P = dense64(nslots), begin = T * P, end = min(begin + P, nslots);
-  uint32_t segCap = wf.capSlots / PT_SEGS, culled = 0;
+  uint32_t segCap = wf.capSlots / PT_SEGS, culled = 0, nConst = 0;
   // PT_RAYGEN_UNROLL slots per lane and pass, phase by phase: the loads of a phase (mask words, then sample counts)
   // are in flight together, so a pass waits through two memory round trips for four slots, not per slot
   constexpr int U = PT_RAYGEN_UNROLL;
@@ -602,7 +602,7 @@ __global__ void __launch_bounds__(PT_RAYGEN_THREADS) k_raygen(SceneBox box, View
 #pragma unroll
     for (int u = 0; u < U; u++) {
       d[u] = v3(0, 0, 0);
-      if (constant[u]) culled++;
+      if (constant[u]) { culled++; nConst++; }
       else if (valid[u]) {
         d[u] = primaryRayFrom(cfg, gp[u], s[u], accW[u], true).d;
         if (!masks.covered) {
@@ -619,8 +619,9 @@ __global__ void __launch_bounds__(PT_RAYGEN_THREADS) k_raygen(SceneBox box, View
       if (enter[u]) wf.slotQ[T * segCap + idx] = f4(d[u], u2f(i[u]));
     }
   }
-  for (int off = 32; off > 0; off >>= 1) culled += __shfl_down(culled, off);
+  for (int off = 32; off > 0; off >>= 1) { culled += __shfl_down(culled, off); nConst += __shfl_down(nConst, off); }
   if ((threadIdx.x & 63) == 0 && culled) statAdd(wf.stats, STAT_RAYS_CULLED, (unsigned long long)culled);
+  if ((threadIdx.x & 63) == 0 && nConst) statAdd(wf.stats, STAT_CONSTANT_SKY, (unsigned long long)nConst);
   __syncthreads();
   if (threadIdx.x == 0) wf.rayOut.count[T] = sCnt;
 }
@@ -873,14 +874,14 @@ __global__ void PT_TRAVERSAL_BOUNDS k_raygen_extend(SceneBox box, ViewMasks mask
   const uint32_t segFirst = (uint32_t)(((uint64_t)blockIdx.x * PT_SEGS) / gridDim.x);
   const uint32_t segLast = (uint32_t)(((uint64_t)(blockIdx.x + 1) * PT_SEGS) / gridDim.x);
   const uint32_t outBase = segFirst * segCapOut, outLimit = (segLast - segFirst) * segCapOut;
-  uint32_t culled = 0, cN = 0, cT = 0, begin;
+  uint32_t culled = 0, nConst = 0, cN = 0, cT = 0, begin;
   while (nextSlots(&pool, wf.taskCounters + (PT_TASK_COUNTERS - 1), nslots, outLimit, begin)) {
     const uint32_t i = begin + (threadIdx.x & 63u);
     const bool valid = i < nslots;
     uint32_t s, gp = slotPixel(cfg, pm, valid ? i : 0u, s);
     const bool constant = valid && masks.constantSky && maskBit(masks.constantSky, gp);
     const bool live = valid && !constant;
-    if (constant) culled++;
+    if (constant) { culled++; nConst++; }
     bool isHit = false; V3 d = v3(0, 0, 0); Hit h; h.t = 0; h.u = 0; h.v = 0; h.tri = 0;
     if (live) {
       d = primaryRayFrom(cfg, gp, s, acc[gp].w, true).d;
@@ -902,8 +903,9 @@ __global__ void PT_TRAVERSAL_BOUNDS k_raygen_extend(SceneBox box, ViewMasks mask
       wf.hitB[e] = make_float4(h.u, h.v, u2f(i), h.t);
     }
   }
-  for (int off = 32; off > 0; off >>= 1) culled += __shfl_down(culled, off);
+  for (int off = 32; off > 0; off >>= 1) { culled += __shfl_down(culled, off); nConst += __shfl_down(nConst, off); }
   if ((threadIdx.x & 63) == 0 && culled) statAdd(wf.stats, STAT_RAYS_CULLED, (unsigned long long)culled);
+  if ((threadIdx.x & 63) == 0 && nConst) statAdd(wf.stats, STAT_CONSTANT_SKY, (unsigned long long)nConst);
   __syncthreads();
   uint32_t n = pool.out;
   for (uint32_t sg = segFirst + threadIdx.x; sg < segLast; sg += blockDim.x) {
@@ -1342,7 +1344,7 @@ __device__ __forceinline__ void shadeVertex(ShadeCtx& cx, const ShadeTables<LDST
 }
 
 // Ray counts of the traced variants: wave sums, one atomic per wave and counter.
-__device__ __forceinline__ void flushTraced(ShadeCtx& cx) {
+__device__ __forceinline__ void flushTraced(ShadeCtx& cx, bool whole = false) {
   uint32_t nInd = cx.nInd, nOccl = cx.nOccl, nEnv = cx.nEnv, nLight = cx.nLight;
   for (int off = 32; off > 0; off >>= 1) {
     nInd += __shfl_down(nInd, off); nOccl += __shfl_down(nOccl, off); nEnv += __shfl_down(nEnv, off); nLight += __shfl_down(nLight, off);
@@ -1353,6 +1355,11 @@ __device__ __forceinline__ void flushTraced(ShadeCtx& cx) {
     if (nInd) { statAdd(st, STAT_RAYS_INDIRECT, (unsigned long long)nInd); statAdd(st, STAT_FUSED_INDIRECT, (unsigned long long)nInd); }
     if (nOccl) { statAdd(st, STAT_RAYS_OCCL, (unsigned long long)nOccl); statAdd(st, STAT_FUSED_OCCL, (unsigned long long)nOccl); }
     if (nEnv) statAdd(st, STAT_ENV_ENTRIES, (unsigned long long)nEnv);
+    if (whole) {
+      if (nLight) statAdd(st, STAT_WHOLE_LIGHT, (unsigned long long)nLight);
+      if (nInd) statAdd(st, STAT_WHOLE_INDIRECT, (unsigned long long)nInd);
+      if (nOccl) statAdd(st, STAT_WHOLE_OCCL, (unsigned long long)nOccl);
+    }
   }
 }
 
@@ -1501,7 +1508,7 @@ __global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_SAMPLE_WAVES) k_sample_t
   ShadeCtx cx{sc, cfg, wf, sCnt, T, segCap, segCap};
   cx.segCapHit = wf.capHit / PT_SEGS; cx.outA = wf.hitOutA; cx.outB = wf.hitOutB;
   cx.segBits = 31u - (uint32_t)__builtin_clz(segsPer);       // the consumers take a segment each: the hits go to all of them in turn
-  uint32_t culled = 0, hits = 0, mine = 0;
+  uint32_t culled = 0, nConst = 0, hits = 0, mine = 0;
   // A workgroup's own runs go to whichever of its waves is free next.  The other runs are a pool that all workgroups
   // take from, PT_POOL_CHUNK at a time, when their own are done (wf.runPool; PT_POOL_COUNTERS counters that deal out
   // every PT_POOL_COUNTERS-th run of the pool each, a workgroup moves on to the next counter when one is used up):
@@ -1558,7 +1565,7 @@ __global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_SAMPLE_WAVES) k_sample_t
     V3 hitPos = v3(0, 0, 0), normal = v3(0, 0, 1), color = v3(0, 0, 0);
     uint32_t matTag = 0, sampleIdx = 0;
     Rng g; g.s0 = 1; g.s1 = 0;
-    if (constant) culled++;
+    if (constant) { culled++; nConst++; }
     if (live) {
       PrimaryRay pr = primaryRayFrom(cfg, gp, s, acc[gp].w, true);
       bool enter;
@@ -1582,16 +1589,20 @@ __global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_SAMPLE_WAVES) k_sample_t
     shadeVertex<true, true, true>(cx, tb, active, hitPos, normal, color, matTag, v3(1, 1, 1), 0u, g, gp, sampleIdx, i);
     if ((threadIdx.x & 63u) == 0) atomicSub(&sBusy, 1u);              // after the run's appends
   }
-  flushTraced(cx);
-  for (int off = 32; off > 0; off >>= 1) { culled += __shfl_down(culled, off); hits += __shfl_down(hits, off); mine += __shfl_down(mine, off); }
+  flushTraced(cx, true);
+  for (int off = 32; off > 0; off >>= 1) {
+    culled += __shfl_down(culled, off); nConst += __shfl_down(nConst, off); hits += __shfl_down(hits, off); mine += __shfl_down(mine, off);
+  }
   if ((threadIdx.x & 63) == 0) {
     if (culled) statAdd(wf.stats, STAT_RAYS_CULLED, (unsigned long long)culled);
+    if (nConst) statAdd(wf.stats, STAT_CONSTANT_SKY, (unsigned long long)nConst);
     if (hits) {
       statAdd(wf.stats, STAT_HITS, (unsigned long long)hits); statAdd(wf.stats, STAT_HITS_PRIMARY, (unsigned long long)hits);
     }
     if (mine > culled) statAdd(wf.stats, STAT_FUSED_PRIMARY, (unsigned long long)(mine - culled));     // view rays traced here
   }
   __syncthreads();
+  if (threadIdx.x == 0 && sCnt[0]) statAdd(wf.stats, STAT_WHOLE_CHAIN_HITS, (unsigned long long)sCnt[0]);
   if (threadIdx.x < segsPer) {
     const uint32_t n = sCnt[0];
     wf.rayOut.count[T + threadIdx.x] = (n + segsPer - 1u - threadIdx.x) >> cx.segBits;      // hit idx went to segment idx % segsPer

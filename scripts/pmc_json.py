@@ -2,7 +2,12 @@
 
   python3 scripts/pmc_json.py <pass dir> <out.json> "<profiled command>"
 
-Per kernel kind (extend, connect, occluded, shade, accumulate; the un-timed visit-counting instances left out):
+One entry per kernel of the render path, named as PtStats.kernelMs names them (pathtracer_amd.PT_K_NAMES); the passes run
+bench.py --no-visits, so every launch the profiler sees belongs to the timed region, and the launch count of every
+kernel is checked against the count bench.py reports for the same run (launch_count_matches).  units_per_launch: the
+kernel's work items per launch in the profiled run (bench.py: kernel_work), so that bytes can be carried over to a run
+with another batch size.
+Per kernel:
   hbm_bytes_per_launch  (2 * FETCH_SIZE + WRITE_SIZE) KiB: on gfx950 FETCH_SIZE tallies the 128-byte requests of wide
                         streaming reads at 64 bytes, so it is doubled; WRITE_SIZE is taken as reported
   cycles_per_launch     GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs)
@@ -31,19 +36,31 @@ def parse(path):
 
 
 def kind_of(name):
-    if name.startswith('k_extend_refill<') or name.startswith('k_raygen_extend<'):
-        return 'extend'
-    if name.startswith('k_shade_occluded<'):
-        return 'occluded'                                   # the traversal kernel that shades the hits it reads
-    if name.startswith('k_shade_traced<') or name.startswith('k_sample_traced'):
-        return 'shade'                                      # shading that traces its own rays; the whole-sample kernel
-    for k in ('extend', 'connect', 'occluded', 'shade', 'accumulate', 'raygen'):
-        if name.startswith('k_' + k + '<') or name == 'k_' + k:
-            if k in ('extend', 'connect', 'occluded') and name.rstrip().endswith(', true>'):
-                return None                                 # COUNT = true: the visit-counting pass
-            if name.startswith('k_extend_primary'):
-                return None
-            return k
+    """PtStats kernel kind of a kernel name as rocprofv3 prints it, None for kernels outside the render path and for the
+    visit-counting instances (COUNT = true: the last template argument of the traversal kernels)."""
+    base = name.split('<')[0].split('(')[0].strip()
+    if base.startswith('void '):
+        base = base[5:]
+    if base.startswith('pt::'):
+        base = base[4:]
+    base = base.split('::')[-1]
+    if base in ('k_extend', 'k_connect', 'k_occluded') and name.rstrip().rstrip(')').split('(')[0].rstrip().endswith(', true>'):
+        return None
+    if base == 'k_shade_traced':
+        return 'shade' if '<true' in name else 'shade_traced'
+    return {'k_extend': 'extend', 'k_extend_refill': 'extend', 'k_connect': 'connect', 'k_occluded': 'occluded', 'k_shade': 'shade',
+            'k_accumulate': 'accumulate', 'k_scan': 'other', 'k_raygen': 'raygen', 'k_raygen_extend': 'raygen_extend',
+            'k_shade_occluded': 'shade_occluded', 'k_sample_traced': 'sample_traced'}.get(base)
+
+
+def bench_line(path):
+    """The JSON line bench.py printed into a pass's log."""
+    try:
+        for line in reversed(open(path).read().splitlines()):
+            if line.startswith('{"metric"'):
+                return json.loads(line)
+    except FileNotFoundError:
+        pass
     return None
 
 
@@ -59,9 +76,18 @@ def main():
                 for c, (n, total) in ctrs.items():
                     tot[k][c] += total; calls[k][c] = calls[k].get(c, 0) + n
     kinds = {}
+    bench = bench_line('%s/fetch.log' % src) or bench_line('%s/sq1.log' % src) or {}
     for k, c in tot.items():
         per = {name: c[name] / max(1, calls[k][name]) for name in c}
         d = {'launches_profiled': max(calls[k].values())}
+        assert min(calls[k].values()) == max(calls[k].values()), 'passes saw different launch counts of %s: %r' % (k, calls[k])
+        bk = (bench.get('kernels') or {}).get(k)
+        if bk:
+            d['launch_count_matches'] = bk['launches'] == d['launches_profiled']
+        bc = ((bench.get('roofline') or {}).get('ceilings') or {}).get(k)
+        if bc:
+            d['units_per_launch'] = bc['units_per_launch']
+            d['algorithmic_hbm_bytes_per_launch_records_only'] = bc['hbm']['algorithmic_bytes_per_launch']
         cyc = per.get('GRBM_GUI_ACTIVE', 0.0) / 8.0
         if cyc:
             d['cycles_per_launch'] = round(cyc)
@@ -89,7 +115,8 @@ def main():
         if per.get('TA_TA_BUSY_sum') and cyc:
             d['ta_busy'] = round(per['TA_TA_BUSY_sum'] / (256.0 * cyc), 4)
         kinds[k] = d
-    json.dump({'command': cmd, 'units': __doc__.split('Per kernel kind', 1)[1].strip(), 'kinds': kinds,
+    json.dump({'command': cmd, 'workload': (bench.get('config') or {}).get('workload'), 'spp': (bench.get('config') or {}).get('spp_per_gpu'),
+               'units': __doc__.split('Per kernel:', 1)[1].strip(), 'kinds': kinds,
                'per_kernel_per_launch': {k: {c: round(v, 1) for c, v in sorted(cs.items())} for k, cs in sorted(kernels.items()) if k.startswith('k_')}},
               open(dst, 'w'), indent=1)
     print(json.dumps(kinds, indent=1))

@@ -2,12 +2,15 @@
 # Everything profiles/ holds for one workload, on the GPU box: the counter passes (each its own profiler process,
 # counters only), the rocprofv3 --kernel-trace --stats summary of the bench command, and the JSON bench.py reads.
 # Usage: scripts/profile_workload.sh <tag> <cN> <workload> <spp of the counter passes> [extra bench args]
+# The counter passes run bench.py --no-visits: no launch of the un-timed visit-counting pass is mixed into a kernel's
+# counters.  <spp> = what one batch of the bench line holds (or the bench line's --spp), so that a profiled launch is a
+# launch of the bench line.
 # Results land in gpurun_out/prof_<tag>_<cN>/; copy <tag>_<cN>_* from there into profiles/.
 set -u
 tag=$1; cn=$2; wl=$3; spp=$4; shift 4
 export TMPDIR=/tmp
 root=$(pwd); out=gpurun_out/prof_${tag}_${cn}; mkdir -p "$out"
-args="--workload $wl --only --spp $spp --steps 1 --warmup 0 --cpu-seconds 0 $*"
+args="--workload $wl --only --no-visits --spp $spp --steps 1 --warmup 0 --cpu-seconds 0 $*"
 pass() {
   name=$1; ctrs=$2
   ( cd /tmp && timeout -s KILL 300 rocprofv3 --pmc $ctrs -d "$root/$out/$name" -o p --output-format csv -- python3 "$root/bench.py" $args > "$root/$out/$name.log" 2>&1 ) || { echo "pass $name failed"; tail -5 "$root/$out/$name.log"; exit 1; }

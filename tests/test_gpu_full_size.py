@@ -89,6 +89,73 @@ def test_c3_chest1_1080p_mode1(require_gpu, flats):
     assert np.array_equal(got['n'], ref['n']) and np.allclose(got['sum'], ref['sum'], rtol=2e-5, atol=1e-7)
 
 
+def test_c4_cornell_3840x2160_and_its_band_split(require_gpu, flats):
+    """configs[3]: the cornell box at 3840x2160 (2 of its 4096 spp).  The frame adds up; a 16-row band equals the
+    oracle's image of that band bit for bit; and the same frame rendered as the reference's 4-scanline tasks
+    (main.d:184-192) shared out over two handles -- the per-GPU shares of a two-GPU run -- reassembles to the same bits."""
+    name, W, H, spp = 'cornell-box', 3840, 2160, 2
+    pt = make_tracer(name, W, H, seed=0x5EED)
+    pt.render_frame(spp)
+    px = pt.read_pixels()
+    st = pt.stats()
+    tri = pt.trace_primary()[0]
+    hits = int((tri >= 0).sum())
+    assert (px['n'] == spp).all() and np.isfinite(px['sum']).all() and (px['sum'] >= 0).all()
+    assert st.samples == W * H * spp and st.raysPrimary == W * H * spp and st.raysOcclusion == 0 and st.raysIndirect == 0
+    assert 0.9 < hits / (W * H) <= 1.0 and 0 < st.raysLight <= st.hitsPrimary and abs(st.hitsPrimary - hits * spp) < 0.01 * hits * spp
+    band0, rows = 1000, 16
+    o = make_oracle(flats[name], name, W, H, has_sky=False, seed=0x5EED)
+    ref = oracle_py.new_pixels(rows * W)
+    o.render_keyed(ref, band0 * W, spp, nthreads=8)
+    got = px[band0 * W:(band0 + rows) * W]
+    assert np.array_equal(got['n'], ref['n']) and np.array_equal(got['sum'].view(np.uint32), ref['sum'].view(np.uint32))
+    assert ref['sum'].max() > 0
+    del pt
+    frame = np.zeros(W * H, P.PIXEL_DTYPE)
+    for r in range(2):
+        part = make_tracer(name, W, H, seed=0x5EED)
+        part.render_bands(4, r, 2, spp)
+        share = part.read_pixels()
+        mine = P.band_rows(H, 4, r, 2)
+        assert (share['n'].reshape(H, W)[mine] == spp).all() and share['n'].sum() == spp * len(mine) * W
+        frame.reshape(H, W)[mine] = share.reshape(H, W)[mine]
+        del part
+    assert np.array_equal(frame['n'], px['n']) and np.array_equal(frame['sum'].view(np.uint32), px['sum'].view(np.uint32))
+
+
+def test_two_handles_driven_from_two_host_threads(require_gpu):
+    """The threading contract of the boundary: functions on one handle are not re-entrant, different handles may be
+    driven from different threads (the reference's workers, main.d:207-215, each call computeOutputColor on their own
+    slice).  Two handles render at once from two host threads, several calls each; each equals its solo render."""
+    import threading
+    specs = [('teapot', 640, 360, dict(has_sky=1, mode=0, seed=21)), ('chest1', 512, 288, dict(has_sky=1, mode=1, seed=22))]
+    solo = []
+    for name, W, H, cfg in specs:
+        pt = make_tracer(name, W, H, **cfg)
+        for _ in range(3):
+            pt.render_frame(2)
+        solo.append(pt.read_pixels()); del pt
+    handles = [make_tracer(name, W, H, **cfg) for name, W, H, cfg in specs]
+    errors = []
+    start = threading.Barrier(2)
+
+    def work(pt):
+        try:
+            start.wait()
+            for _ in range(3):
+                pt.render_frame(2)
+            pt.synchronize()
+        except Exception as e:                                        # reported below, in the test's thread
+            errors.append(e)
+    th = [threading.Thread(target=work, args=(pt,)) for pt in handles]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errors, errors
+    for pt, ref in zip(handles, solo):
+        got = pt.read_pixels()
+        assert np.array_equal(got['n'], ref['n']) and np.array_equal(got['sum'].view(np.uint32), ref['sum'].view(np.uint32))
+
+
 def test_headless_driver_image_and_project_file(require_gpu, flats):
     """The native caller (csrc/headless_main.cpp, the stand-in for main.d:142-345): loadScene, N passes of one sample
     per pixel with the reference's timing lines, tone map to a PPM, raw Pixel[] project file.  It ran as a child process

@@ -403,6 +403,26 @@ def test_repeated_small_passes_replayed_from_a_graph_equal_one_render(require_gp
     assert np.array_equal(a.read_pixels()['sum'].view(np.uint32), b.read_pixels()['sum'].view(np.uint32))
 
 
+@pytest.mark.parametrize('name,sky,mode', [('cornell-box', 0, 0), ('chest1', 1, 1)])
+def test_repeated_small_passes_on_a_stream_of_the_caller(require_gpu, name, sky, mode):
+    """ptgpu_set_stream hands the handle a stream of the caller's -- here the legacy null stream (what
+    torch.cuda.current_stream() is by default), which cannot be captured, and a torch stream.  Repeated identical small
+    passes run as ordinary launches there; three passes equal one render of three samples."""
+    import torch
+    W, H = 160, 120
+    want = make_tracer(name, W, H, has_sky=sky, mode=mode, seed=23, flags=P.PT_FLAG_NO_GRAPH); want.render_frame(4)
+    ref = want.read_pixels()
+    side = torch.cuda.Stream()
+    for stream in (0, side.cuda_stream):
+        pt = make_tracer(name, W, H, has_sky=sky, mode=mode, seed=23)
+        pt.set_stream(stream)
+        for _ in range(4):
+            pt.render_frame(1)
+        got = pt.read_pixels()
+        assert np.array_equal(got['n'], ref['n']) and np.array_equal(got['sum'].view(np.uint32), ref['sum'].view(np.uint32))
+        pt.close()
+
+
 @pytest.mark.parametrize('name,sky,mode', [('chest1', 1, 0), ('chest1', 1, 1), ('cornell-box', 0, 1), ('cornell-box', 1, 1),
                                            ('cornell-box', 1, 0)])
 def test_shading_that_traces_its_own_rays_equals_the_queued_path(require_gpu, name, sky, mode):
@@ -434,6 +454,9 @@ def test_shading_that_traces_its_own_rays_equals_the_queued_path(require_gpu, na
     assert sa.kernelLaunches[k.index('extend')] == 0 and sc.kernelLaunches[k.index('extend')] == 2      # view rays of two batches
     assert sb.kernelLaunches[k.index('extend')] == (2 if mode == 0 else 2 * (2 + 4))
     assert sa.kernelLaunches[k.index('occluded')] == 0 and sa.kernelLaunches[k.index('connect')] == 0
+    assert sa.kernelLaunches[k.index('sample_traced')] == 2 and sa.kernelLaunches[k.index('shade_traced')] == (2 if mode == 1 else 0)
+    assert sa.raysIndirectInSample + sa.raysOcclusionInSample + sa.raysLightInSample > 0 and sc.raysIndirectInSample == 0
+    assert sa.raysIndirectInSample <= sa.raysIndirectInShade and sa.raysOcclusionInSample <= sa.raysOcclusionInShade
     assert (sb.kernelLaunches[k.index('occluded')] > 0) == bool(sky) and (sb.kernelLaunches[k.index('connect')] > 0) == lights
 
 
@@ -506,4 +529,5 @@ def test_traversal_kernel_that_shades_its_hits_equals_the_queued_path(require_gp
     assert sa.raysOcclusion > 0 and sa.hits > 0
     k = list(P.PT_K_NAMES)
     assert sa.kernelLaunches[k.index('shade')] == 0 and sb.kernelLaunches[k.index('shade')] == 2
-    assert sa.kernelLaunches[k.index('occluded')] == 2 and sb.kernelLaunches[k.index('occluded')] == 2
+    assert sa.kernelLaunches[k.index('shade_occluded')] == 2 and sa.kernelLaunches[k.index('occluded')] == 0
+    assert sb.kernelLaunches[k.index('occluded')] == 2 and sb.kernelLaunches[k.index('shade_occluded')] == 0
