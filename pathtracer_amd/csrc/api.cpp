@@ -423,7 +423,7 @@ void ensureWavefront(PtHandle* h) {
   // queue bookkeeping: stage s owns 2 + PT_MAX_KINDS queues: [0] the hit queue its extend fills, [1] the ray queue
   // and [2 + kind] the shadow queues its shade fills
   const uint32_t perStage = 2 + PT_MAX_KINDS;
-  h->bCounters.alloc((size_t)rounds * perStage * PT_QMETA_WORDS * 4 + (PT_TASK_COUNTERS + PT_POOL_WORDS) * 4);
+  h->bCounters.alloc((size_t)rounds * perStage * PT_QMETA_WORDS * 4 + (PT_TASK_WORDS + PT_POOL_WORDS) * 4);
   h->bMetaDesc.alloc((size_t)rounds * perStage * sizeof(QMeta));
   h->metas.resize((size_t)rounds * perStage);
   uint32_t* words = h->bCounters.as<uint32_t>();
@@ -434,7 +434,7 @@ void ensureWavefront(PtHandle* h) {
   HIPCHECK(hipMemset(h->bCounters.p, 0, h->bCounters.bytes));
   HIPCHECK(hipMemcpy(h->bMetaDesc.p, h->metas.data(), h->metas.size() * sizeof(QMeta), hipMemcpyHostToDevice));
   w.taskCounters = words + h->metas.size() * PT_QMETA_WORDS;
-  w.runPool = (h->cfg.flags & PT_FLAG_STATIC_RUNS) ? nullptr : w.taskCounters + PT_TASK_COUNTERS;
+  w.runPool = (h->cfg.flags & PT_FLAG_STATIC_RUNS) ? nullptr : w.taskCounters + PT_TASK_WORDS;
   w.slotQ = h->bSlotQ.as<float4>(); w.hitA = h->bHitA.as<float4>(); w.hitB = h->bHitB.as<float4>();
   w.rayO = h->bRayO.as<float4>(); w.rayD = h->bRayD.as<float4>();
   w.Lacc = h->bLacc.as<float4>(); w.thr = h->bThr.as<float4>(); w.rng = h->bRng.as<uint2>();
@@ -915,7 +915,7 @@ NoAllocLayout layoutNoAlloc(const PtHandle* h, uint32_t capSlots) {
   const uint64_t sh = L.lean ? 16 : (uint64_t)L.kinds * capQueue * 16;
   L.shO = piece(sh); L.shD = piece(sh); L.shW = piece(sh); L.shX = piece(L.lean ? 16 : capQueue * 16);
   const uint64_t nMetas = (uint64_t)L.rounds * (2 + PT_MAX_KINDS);
-  L.words = piece(nMetas * PT_QMETA_WORDS * 4 + (PT_TASK_COUNTERS + PT_POOL_WORDS) * 4);
+  L.words = piece(nMetas * PT_QMETA_WORDS * 4 + (PT_TASK_WORDS + PT_POOL_WORDS) * 4);
   L.desc = piece(nMetas * sizeof(QMeta));
   L.total = at;
   return L;
@@ -966,7 +966,7 @@ int ptgpu_render_noalloc(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount,
       h->metasNoAlloc[m] = QMeta{p, p + PT_SEGS, p + 2 * PT_SEGS + 2};
     }
     w.taskCounters = words + nMetas * PT_QMETA_WORDS;
-    w.runPool = (h->cfg.flags & PT_FLAG_STATIC_RUNS) ? nullptr : w.taskCounters + PT_TASK_COUNTERS;
+    w.runPool = (h->cfg.flags & PT_FLAG_STATIC_RUNS) ? nullptr : w.taskCounters + PT_TASK_WORDS;
     ws.hostMetas = h->metasNoAlloc.data(); ws.devMetas = (const QMeta*)(base + L.desc);
     // masks built for the current scene and camera are used; none is built here (that would allocate): the view rays
     // are then culled by the scene's bounding box, which gives the same image
@@ -980,7 +980,7 @@ int ptgpu_render_noalloc(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount,
     const bool ordered = cap == hipStreamCaptureStatusNone;
     if (ordered) HIPCHECK(hipStreamWaitEvent(h->stream, g_scratchDone[h->cfg.device], 0));
     // the array keeps the last call's contents (of this or any other handle on the device): counters start at zero
-    HIPCHECK(hipMemsetAsync(words, 0, nMetas * PT_QMETA_WORDS * 4 + (PT_TASK_COUNTERS + PT_POOL_WORDS) * 4, h->stream));
+    HIPCHECK(hipMemsetAsync(words, 0, nMetas * PT_QMETA_WORDS * 4 + (PT_TASK_WORDS + PT_POOL_WORDS) * 4, h->stream));
     // ... and so do the chain lanes' radiance records: whatever another call's layout left there must not be taken
     // for a record of this batch
     if (L.lanes > 1)

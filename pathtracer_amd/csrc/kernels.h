@@ -106,7 +106,12 @@ struct QMeta {
   uint32_t* start;            // [PT_SEGS]      segment that holds flat entry T*P: where consumer block-task T starts
 };
 constexpr uint32_t PT_QMETA_WORDS = 3 * PT_SEGS + 2;
-constexpr int PT_TASK_COUNTERS = 16;   // one dynamic work counter per traversal launch of a stage
+constexpr int PT_TASK_COUNTERS = 16;   // one dynamic work counter per traversal launch of a stage ...
+// ... which is PT_TASK_PARTS words: a launch's queue is cut into that many contiguous parts with a counter each, and a
+// workgroup starts with the part of its index modulo PT_TASK_PARTS -- workgroups are dealt to the 8 XCDs in turn, so the
+// workgroups that share an XCD (and its L2) work their way through one contiguous part of the queue together instead of
+// every L2 seeing rays from all over the queue; a workgroup whose part is used up goes on with the next one.
+constexpr int PT_TASK_PARTS = 8, PT_TASK_WORDS = PT_TASK_COUNTERS * PT_TASK_PARTS;
 // Counters of the runs that the whole-sample kernel's workgroups take from a common pool (k_sample_traced), each on a
 // cache line of its own; they follow the task counters and are zero between batches (k_accumulate clears them).
 constexpr int PT_POOL_COUNTERS = 8, PT_POOL_STRIDE = 64, PT_POOL_WORDS = PT_POOL_COUNTERS * PT_POOL_STRIDE;
@@ -142,7 +147,8 @@ struct Wavefront {
   QMeta hitQ;                 // hit queue of this stage: extend fills it, shade reads it
   QMeta rayOut;               // ray queue this stage's shade fills
   QMeta sh[PT_MAX_KINDS];     // shadow queues this stage's shade fills
-  uint32_t* taskCounters;     // [PT_TASK_COUNTERS], zeroed by the scan that precedes the launches using them
+  uint32_t* taskCounters;     // [PT_TASK_WORDS], zeroed by the scan that precedes the launches using them; counter c of
+                              // a stage = words [c * PT_TASK_PARTS, (c + 1) * PT_TASK_PARTS)
   uint32_t* runPool;          // [PT_POOL_WORDS] or null (every workgroup keeps to its own share of the runs)
   unsigned long long* stats;  // see STAT_*
   uint32_t capSlots;          // primary slots per batch (multiple of 64 * PT_SEGS)

@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(1024) k_scan(const QMeta* __restrict__ metas, 
   __shared__ uint32_t wsum[16];
   QMeta q = metas[blockIdx.x];
   uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (blockIdx.x == 0 && tid < PT_TASK_COUNTERS) taskCounters[tid] = 0;
+  if (blockIdx.x == 0 && tid < PT_TASK_WORDS) taskCounters[tid] = 0;
   uint32_t c = q.count[tid], x = c;
   for (int off = 1; off < 64; off <<= 1) { uint32_t y = __shfl_up(x, off); if (lane >= (uint32_t)off) x += y; }   // inclusive in wave
   if (lane == 63) wsum[wave] = x;
@@ -473,11 +473,18 @@ __device__ __forceinline__ uint32_t physIndexHint(const QMeta& q, uint32_t j, ui
 // the workgroup's waves take 64 at a time from the LDS pool: state = (end << 32) | next, advanced by a 64-bit
 // compare-and-swap.  Only the wave that holds `lock` refills, and only an empty pool is ever refilled, so a
 // successful compare-and-swap always advanced the range it read.  Waves never wait for each other between chunks.
-struct WorkPool { unsigned long long state; uint32_t lock, done, seg, out; };
+struct WorkPool { unsigned long long state; uint32_t lock, done, seg, out, partsDone; };
+#ifndef PT_XCD_PARTS
+#define PT_XCD_PARTS PT_TASK_PARTS      // diagnostic builds: 1 = one counter for the whole queue
+#endif
+// First entry of part p of a queue of `total` entries (whole waves).
+__device__ __forceinline__ uint32_t partBegin(uint32_t total, uint32_t p) {
+  return p >= PT_XCD_PARTS ? total : (uint32_t)(((uint64_t)total * p / PT_XCD_PARTS) & ~63ull);
+}
 struct Chunk { uint32_t begin, end, seg; };
 
 __device__ __forceinline__ void initPool(WorkPool* p) {
-  if (threadIdx.x == 0) { p->state = 0; p->lock = 0; p->done = 0; p->seg = 0; p->out = 0; }
+  if (threadIdx.x == 0) { p->state = 0; p->lock = 0; p->done = 0; p->seg = 0; p->out = 0; p->partsDone = 0; }
 }
 
 // Next chunk for the calling wave (wave-uniform result); false when the queue is drained.  outLimit != 0: the
@@ -504,12 +511,21 @@ __device__ __forceinline__ bool nextChunk(WorkPool* p, uint32_t* counter, const 
           // a short queue is handed out in smaller pieces, so that every workgroup of the launch gets some of it: with
           // PT_SUPER entries a piece, 76 800 rays (a 320 x 240 pass) would keep 38 workgroups busy and leave the rest idle
           const uint32_t piece = min(PT_SUPER, max(blockDim.x, ((total + gridDim.x - 1) / gridDim.x + 63u) & ~63u));
-          uint32_t g = full ? 0xFFFFFFFFu : atomicAdd(counter, piece);
-          if (g >= total) vp->done = 1;
+          // the next piece of the part this workgroup is working through (the part of its index first, then the others
+          // in turn)
+          uint32_t g = 0xFFFFFFFFu, gEnd = 0;
+          while (!full && vp->partsDone < PT_XCD_PARTS) {
+            const uint32_t part = (blockIdx.x + vp->partsDone) % PT_XCD_PARTS;
+            const uint32_t lo = partBegin(total, part), hi = partBegin(total, part + 1);
+            const uint32_t off = lo < hi ? atomicAdd(counter + part, piece) : 0xFFFFFFFFu;
+            if (off < hi - lo) { g = lo + off; gEnd = min(g + piece, hi); break; }
+            vp->partsDone = vp->partsDone + 1;
+          }
+          if (g == 0xFFFFFFFFu) vp->done = 1;
           else {
             vp->seg = q.start[g / q.prefix[PT_SEGS + 1]];
             __threadfence_block();
-            atomicExch(&p->state, ((unsigned long long)min(g + piece, total) << 32) | g);
+            atomicExch(&p->state, ((unsigned long long)gEnd << 32) | g);
           }
         }
         __threadfence_block();
@@ -763,20 +779,56 @@ struct WaveSupply {
   }
 };
 
+// Where its hits go: the hit of input entry j goes to output segment j / P, P being the input queue's entries per
+// block-task -- the hit queue then lists the hits in the order of the rays (to 1/PT_SEGS of the queue), which for view
+// rays is the order of the pixel tiles.  What shade makes of it keeps that order, so the light-sample and sun / sky rays
+// that a wave, a workgroup and -- with the queue parts of nextChunk -- an XCD have in flight start close to each other
+// and share the nodes and triangles they fetch.  (With one output region per workgroup, as the kernels for scenes in
+// LDS have it, a region is a sample of the whole launch, and the rays in flight in the next stage come from all over
+// the frame.)  A segment takes at most P hits, fewer than it holds; lanes of a wave that append to the same segment
+// share one atomic add on its count (a wave's rays come from one or two chunks, so from one or two segments).
+// The counts must be zero at launch (launchExtend clears them).
+#ifndef PT_EXTEND_BY_SEGMENT
+#define PT_EXTEND_BY_SEGMENT 1
+#endif
+__device__ __forceinline__ uint32_t appendToSegment(bool isHit, uint32_t seg, uint32_t* counts) {
+  uint32_t idx = 0;
+  bool pending = isHit;
+  const uint32_t lane = threadIdx.x & 63u;
+  for (;;) {
+    const unsigned long long todo = __ballot(pending);
+    if (!todo) break;
+    const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)seg, (int)leader);
+    const bool mine = pending && seg == s0;
+    const unsigned long long m = __ballot(mine);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&counts[s0], (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+    if (mine) { idx = base + rank; pending = false; }
+  }
+  return idx;
+}
+
 template <bool PRIMARY>
 __global__ void PT_TRAVERSAL_BOUNDS k_extend_refill(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, Wavefront wf) {
   __shared__ __align__(16) WorkPool pool;
   initPool(&pool);
   __syncthreads();
   const QMeta q = wf.rayIn;
-  const uint32_t total = q.prefix[PT_SEGS];
+  const uint32_t total = q.prefix[PT_SEGS], perTask = max(q.prefix[PT_SEGS + 1], 1u);
   const uint32_t segCapIn = (PRIMARY ? wf.capSlots : wf.capQueue) / PT_SEGS, segCapOut = wf.capHit / PT_SEGS;
+#if PT_EXTEND_BY_SEGMENT
+  const uint32_t outLimit = 0;
+#else
   const uint32_t segFirst = (uint32_t)(((uint64_t)blockIdx.x * PT_SEGS) / gridDim.x);
   const uint32_t segLast = (uint32_t)(((uint64_t)(blockIdx.x + 1) * PT_SEGS) / gridDim.x);
   const uint32_t outBase = segFirst * segCapOut, outLimit = (segLast - segFirst) * segCapOut;
+#endif
   if (!PRIMARY && blockIdx.x == 0 && threadIdx.x == 0) statAdd(wf.stats, STAT_RAYS_INDIRECT, (unsigned long long)total);
   SegCursor cur; cur.seg = 0; cur.lo = 1; cur.hi = 0;
-  bool hasRay = false; uint32_t slot = 0; float carry = 0.0f;
+  bool hasRay = false; uint32_t slot = 0, jIn = 0; float carry = 0.0f;
   LaneTrav t; idleTrav(t);
   uint32_t stack[64];
   WaveSupply sup;
@@ -794,16 +846,22 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend_refill(DevScene sc, DevCfg cfg, Pix
           float4 ro = wf.rayO[e], rd = wf.rayD[e];
           slot = f2u(ro.w); carry = rd.w; startTrav(sc, t, xyz(ro), xyz(rd));
         }
-        hasRay = true; need = false;
+        hasRay = true; need = false; jIn = j;
       }
     }
     if (!__any(hasRay)) break;
     advanceTrav<false>(sc, t, stack, cfg.eps, sup.open ? (uint32_t)PT_REFILL_BELOW : 1u);
     const bool fin = hasRay && !t.busy();
     const bool isHit = fin && t.found;
-    uint32_t idx = waveAppend(isHit, &pool.out);
+#if PT_EXTEND_BY_SEGMENT
+    const uint32_t seg = min(jIn / perTask, PT_SEGS - 1u);
+    const uint32_t idx = appendToSegment(isHit, seg, wf.hitQ.count);
+    const uint32_t e = seg * segCapOut + idx;
+#else
+    const uint32_t idx = waveAppend(isHit, &pool.out);
+    const uint32_t e = outBase + idx;
+#endif
     if (isHit) {
-      uint32_t e = outBase + idx;
       wf.hitA[e] = f4(t.o + t.d * t.h.t, u2f(t.h.tri));
       wf.hitB[e] = make_float4(t.h.u, t.h.v, u2f(slot), PRIMARY ? t.h.t : carry);
     } else if (fin && PRIMARY) {
@@ -811,12 +869,14 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend_refill(DevScene sc, DevCfg cfg, Pix
     }
     if (fin) hasRay = false;
   }
+#if !PT_EXTEND_BY_SEGMENT
   __syncthreads();
   uint32_t n = pool.out;
   for (uint32_t s = segFirst + threadIdx.x; s < segLast; s += blockDim.x) {
     uint32_t before = (s - segFirst) * segCapOut;
     wf.hitQ.count[s] = n > before ? min(n - before, segCapOut) : 0u;
   }
+#endif
 }
 
 // (The same scheme in k_connect and k_occluded was measured on the 10 M-triangle soup and dropped: 25.5 -> 27.1 ms and
@@ -875,7 +935,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_raygen_extend(SceneBox box, ViewMasks mask
   const uint32_t segLast = (uint32_t)(((uint64_t)(blockIdx.x + 1) * PT_SEGS) / gridDim.x);
   const uint32_t outBase = segFirst * segCapOut, outLimit = (segLast - segFirst) * segCapOut;
   uint32_t culled = 0, nConst = 0, cN = 0, cT = 0, begin;
-  while (nextSlots(&pool, wf.taskCounters + (PT_TASK_COUNTERS - 1), nslots, outLimit, begin)) {
+  while (nextSlots(&pool, wf.taskCounters + (PT_TASK_COUNTERS - 1) * PT_TASK_PARTS, nslots, outLimit, begin)) {
     const uint32_t i = begin + (threadIdx.x & 63u);
     const bool valid = i < nslots;
     uint32_t s, gp = slotPixel(cfg, pm, valid ? i : 0u, s);
@@ -1630,7 +1690,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_shade_occluded(DevScene sc, DevCfg cfg, Pi
   uint32_t nRays = 0, nEnv = 0, cN = 0, cT = 0;
   SegCursor cur; cur.seg = 0; cur.lo = 1; cur.hi = 0;
   Chunk ck;
-  while (nextChunk(&pool, wf.taskCounters + 1, q, total, 0, ck)) {
+  while (nextChunk(&pool, wf.taskCounters + 1 * PT_TASK_PARTS, q, total, 0, ck)) {
     uint32_t j = ck.begin + (threadIdx.x & 63u);
     if (j < ck.end) {
       uint32_t e = physIndexHint(q, j, ck.seg, segCap, cur);
@@ -1851,7 +1911,12 @@ struct Geo { dim3 grid, block; size_t lds; };
 Geo traversalGeo(const LaunchCfg& lc, const DevScene& sc, uint64_t maxItems) {
   Geo g; g.lds = sc.ldsBytes;
   uint32_t bs, perCU;
-  if (sc.ldsBytes == 0) { bs = 512; perCU = 4; }
+  if (sc.ldsBytes == 0) {
+    bs = 512; perCU = 4;
+#ifdef PT_DIAG_ENV
+    if (const char* e = getenv("PT_DIAG_PERCU")) perCU = (uint32_t)atoi(e);      // diagnostic builds: occupancy of the global-memory kernels
+#endif
+  }
   else { perCU = std::max(1u, ldsWorkgroupsPerCU(sc.ldsBytes)); bs = perCU == 8 ? 256 : perCU == 4 ? 512 : 1024; }
   uint64_t want = (maxItems + bs - 1) / bs;
   uint64_t cap = (uint64_t)lc.numCUs * perCU;
@@ -1904,7 +1969,10 @@ static void dispatchExtend(const LaunchCfg& lc, const DevScene& sc, const DevCfg
   if (l_ && c_) { allowLds(lc, (const void*)k_extend<PRIMARY, true, true>, g.lds); hipLaunchKernelGGL((k_extend<PRIMARY, true, true>), g.grid, g.block, g.lds, lc.stream, sc, cfg, pm, acc, wf); }
   else if (l_) { allowLds(lc, (const void*)k_extend<PRIMARY, true, false>, g.lds); hipLaunchKernelGGL((k_extend<PRIMARY, true, false>), g.grid, g.block, g.lds, lc.stream, sc, cfg, pm, acc, wf); }
   else if (c_) hipLaunchKernelGGL((k_extend<PRIMARY, false, true>), g.grid, g.block, 0, lc.stream, sc, cfg, pm, acc, wf);
-  else if (PT_REFILL_BELOW) hipLaunchKernelGGL((k_extend_refill<PRIMARY>), g.grid, g.block, 0, lc.stream, sc, cfg, pm, acc, wf);
+  else if (PT_REFILL_BELOW) {
+    if (PT_EXTEND_BY_SEGMENT) (void)hipMemsetAsync(wf.hitQ.count, 0, PT_SEGS * sizeof(uint32_t), lc.stream);   // it adds to them
+    hipLaunchKernelGGL((k_extend_refill<PRIMARY>), g.grid, g.block, 0, lc.stream, sc, cfg, pm, acc, wf);
+  }
   else hipLaunchKernelGGL((k_extend<PRIMARY, false, false>), g.grid, g.block, 0, lc.stream, sc, cfg, pm, acc, wf);
 }
 
@@ -1917,7 +1985,7 @@ void launchConnect(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, c
   Geo g = traversalGeo(lc, sc, wf.capQueue);
   size_t e = (size_t)kind * wf.capQueue;
   PT_DISPATCH_LC(k_connect, sc, cfg.eps, wf.sh[kind], wf.capQueue / PT_SEGS, (const float4*)(wf.shO + e), (const float4*)(wf.shD + e),
-                 (const float4*)(wf.shW + e), wf.taskCounters + 1 + kind, area, wf.Lacc, wf.capSlots, wf.tag, wf.stats);
+                 (const float4*)(wf.shW + e), wf.taskCounters + (1 + kind) * PT_TASK_PARTS, area, wf.Lacc, wf.capSlots, wf.tag, wf.stats);
 }
 
 void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, bool primary) {
@@ -1925,7 +1993,7 @@ void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, 
   size_t e = (size_t)kind * wf.capQueue;
   PT_DISPATCH_LC(k_occluded, sc, cfg.eps, cfg.sunRadiance, cfg.skyRadiance, envDirect(cfg, sc, primary) ? 1 : 0, wf.sh[kind],
                  wf.capQueue / PT_SEGS, (const float4*)(wf.shO + e), (const float4*)(wf.shD + e), (const float4*)(wf.shW + e),
-                 (const float4*)wf.shX, wf.taskCounters + 1 + kind, wf.Lacc, wf.capSlots, wf.tag, wf.stats);
+                 (const float4*)wf.shX, wf.taskCounters + (1 + kind) * PT_TASK_PARTS, wf.Lacc, wf.capSlots, wf.tag, wf.stats);
 }
 
 void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
