@@ -217,7 +217,7 @@ def measure(P, torch, dist, multigpu, name, args, rank, world, local_rank, rehea
     spp = args.spp or wl['spp']
     W, H = wl['W'], wl['H']
     model = os.path.join(ROOT, 'tests', 'golden', 'models', wl['model'] + '.thModel')
-    bvh_flag = {'auto': 0, 'gpu': P.PT_FLAG_GPU_BVH, 'host': P.PT_FLAG_HOST_BVH}[args.bvh]
+    bvh_flag = {'auto': 0, 'gpu': P.PT_FLAG_GPU_BVH, 'host': P.PT_FLAG_HOST_BVH}[args.bvh] | args.flags
 
     acc = torch.zeros(W * H * 4, dtype=torch.float32, device='cuda')
     pt = P.PathTracer(W, H, device=local_rank, has_sky=wl['sky'], mode=wl['mode'], seed=0x5EED,
@@ -387,6 +387,7 @@ def main():
     ap.add_argument('--max-leaf', type=int, default=0)
     ap.add_argument('--soup-tris', type=int, default=10_000_000, help='triangles of the synthetic soup workload')
     ap.add_argument('--bvh', default='auto', choices=['auto', 'gpu', 'host'], help='where the BVH is built (auto: GPU from 1 M triangles)')
+    ap.add_argument('--flags', type=int, default=0, help='extra PT_FLAG_* bits (A/B runs: e.g. 2048 = binary tree for scenes in global memory)')
     ap.add_argument('--no-visits', action='store_true', help='skip the un-timed visit-counting pass (counter passes under the profiler)')
     ap.add_argument('--only', action='store_true', help='measure only --workload (no other_workloads, no pass latency)')
     args = ap.parse_args()
