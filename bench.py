@@ -387,7 +387,7 @@ def main():
     ap.add_argument('--max-leaf', type=int, default=0)
     ap.add_argument('--soup-tris', type=int, default=10_000_000, help='triangles of the synthetic soup workload')
     ap.add_argument('--bvh', default='auto', choices=['auto', 'gpu', 'host'], help='where the BVH is built (auto: GPU from 1 M triangles)')
-    ap.add_argument('--flags', type=int, default=0, help='extra PT_FLAG_* bits (A/B runs: e.g. 2048 = binary tree for scenes in global memory)')
+    ap.add_argument('--flags', type=int, default=0, help='extra PT_FLAG_* bits (A/B runs)')
     ap.add_argument('--no-visits', action='store_true', help='skip the un-timed visit-counting pass (counter passes under the profiler)')
     ap.add_argument('--only', action='store_true', help='measure only --workload (no other_workloads, no pass latency)')
     args = ap.parse_args()

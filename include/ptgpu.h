@@ -91,10 +91,6 @@ typedef struct PtConfig {
                                      (default: pairs are laid out so that a 128-byte line holds a pair with
                                      descendants of it)                                                              */
 
-#define PT_FLAG_NO_WIDE_NODES 2048u  /* scenes traversed from global memory: walk the binary tree (16-byte nodes on a 16-bit
-                                     grid, sibling pairs; see PT_FLAG_NO_TREELETS).  Default: the same tree as nodes of
-                                     up to eight children, a 128-byte line each, child boxes on an 8-bit grid of the node  */
-
 typedef struct PtMaterial { float emissive; float color[3]; } PtMaterial;        /* rendering.d:33-37 */
 typedef struct PtPixel { float color[3]; float n; float sum[3]; } PtPixel;        /* rendering.d:24-30 */
 
@@ -140,8 +136,6 @@ typedef struct PtStats {
   double bvhBuildSeconds;    /* wall time of that build (host or GPU, transfers included)                 */
   double maskBuildMs;        /* host time of the last build + upload of the view-ray masks (done inside the first
                                 ptgpu_render after the scene or the camera changed)                         */
-  uint32_t numWideNodes;     /* nodes of the eight-wide tree the kernels walk (0: they walk the binary tree)  */
-  uint32_t wideDepth;        /* its depth                                                                  */
 } PtStats;
 
 const char* ptgpu_last_error(void);
@@ -171,15 +165,8 @@ int ptgpu_get_scene(PtHandle* h, float* v, float* n, uint32_t* matIdx, PtMateria
 int ptgpu_get_light_group(PtHandle* h, uint32_t g, float* rows11, uint32_t cap, uint32_t* count, float* totalArea);
 /* Flattened BVH: nodes = numNodes x 8 floats (min.xyz, ref, max.xyz, unused), refs as uint32 bit patterns;
  * triOrder = numTriangles original triangle ids in leaf order.  When the scene is traversed from global memory
- * with PT_FLAG_NO_WIDE_NODES the boxes are the ones the kernels use: rounded outwards to a 16-bit grid over the root box. */
+ * (PtStats.sceneInLds == 0) the boxes are the ones the kernels use: rounded outwards to a 16-bit grid over the root box. */
 int ptgpu_get_bvh(PtHandle* h, float* nodes8, uint32_t* triOrder);
-/* The eight-wide form of that tree, which the kernels walk when the scene is traversed from global memory (unless
- * PT_FLAG_NO_WIDE_NODES; then, or with the scene in LDS: PT_E_STATE; ptgpu_get_bvh then returns the binary tree's own
- * float boxes).  nodes32 = PtStats.numWideNodes x 32 words: origin.xyz (float bits), three cell-size exponents, child
- * boxes on the node's 8-bit grid, eight child references (0xFFFFFFFF: none; count << 28 | first triangle as in the
- * binary tree; else a wide node).  childBoxes48 = per node 8 x (min.xyz, max.xyz): the boxes those bytes stand for.
- * Replaces the bounding spheres of Scene.Node (scene.d:145-156) on that path.  Either pointer may be NULL. */
-int ptgpu_get_wide_nodes(PtHandle* h, uint32_t* nodes32, float* childBoxes48);
 
 /* Exactly Camera's private state (camera.d:11-12) ... */
 int ptgpu_set_camera(PtHandle* h, const float pos[3], const float dir[3], const float right[3], const float up[3],

@@ -9,7 +9,6 @@ LIB_PATH = os.environ.get('PTGPU_LIBRARY') or os.path.join(_HERE, 'libptgpu.so')
 PT_OK, PT_E_INVALID, PT_E_STATE, PT_E_DEVICE, PT_E_IO, PT_E_NOMEM = 0, -1, -2, -3, -4, -5
 PT_FLAG_COUNT_VISITS, PT_FLAG_NO_LDS_SCENE, PT_FLAG_TIME_KERNELS, PT_FLAG_NO_COVERAGE_MASK = 1, 2, 4, 8
 PT_FLAG_GPU_BVH, PT_FLAG_HOST_BVH, PT_FLAG_NO_GRAPH, PT_FLAG_NO_FUSE, PT_FLAG_QUEUED_VIEW_RAYS, PT_FLAG_NO_TREELETS, PT_FLAG_STATIC_RUNS = 16, 32, 64, 128, 256, 1024, 512
-PT_FLAG_NO_WIDE_NODES = 2048
 PT_K_NAMES = ('extend', 'connect', 'occluded', 'shade', 'accumulate', 'other', 'raygen', 'raygen_extend', 'shade_occluded',
               'shade_traced', 'sample_traced')
 
@@ -34,8 +33,7 @@ class PtStats(C.Structure):
                 ('kernelMs', C.c_double * 11), ('kernelLaunches', C.c_uint64 * 11), ('renderMs', C.c_double),
                 ('numTriangles', C.c_uint32), ('numNodes', C.c_uint32), ('bvhDepth', C.c_uint32),
                 ('numLightGroups', C.c_uint32), ('sceneInLds', C.c_uint32), ('bvhOnGpu', C.c_uint32),
-                ('bvhBuildSeconds', C.c_double), ('maskBuildMs', C.c_double),
-                ('numWideNodes', C.c_uint32), ('wideDepth', C.c_uint32)]
+                ('bvhBuildSeconds', C.c_double), ('maskBuildMs', C.c_double)]
 
 
 # every symbol include/ptgpu.h declares: name -> (restype, argtypes)
@@ -50,7 +48,6 @@ SYMBOLS = {
     'ptgpu_get_scene': (_I, [_VP, _VP, _VP, _VP, _VP, _VP]),
     'ptgpu_get_light_group': (_I, [_VP, _U32, _VP, _U32, _VP, _VP]),
     'ptgpu_get_bvh': (_I, [_VP, _VP, _VP]),
-    'ptgpu_get_wide_nodes': (_I, [_VP, _VP, _VP]),
     'ptgpu_set_camera': (_I, [_VP, _VP, _VP, _VP, _VP, _F, _F]),
     'ptgpu_camera_look_at': (_I, [_VP, _F, _F, _VP, _VP, _VP, _VP]),
     'ptgpu_render': (_I, [_VP, _U32, _U32, _U32]),

@@ -159,13 +159,6 @@ class PathTracer:
         self._check(self.lib.ptgpu_get_bvh(self.h, _ptr(nodes), _ptr(order)))
         return nodes, order
 
-    def get_wide_nodes(self):
-        """The eight-wide tree of a scene traversed from global memory: (nodes [N, 32] uint32, child boxes [N, 8, 6])."""
-        n = self.stats().numWideNodes
-        nodes = np.zeros((max(n, 1), 32), np.uint32); boxes = np.zeros((max(n, 1), 8, 6), np.float32)
-        self._check(self.lib.ptgpu_get_wide_nodes(self.h, _ptr(nodes), _ptr(boxes)))
-        return nodes[:n], boxes[:n]
-
     def set_camera(self, cam):
         """cam: Camera (after setTransform) or 14 floats pos dir right up tanFov aspect (camera.d:11-12)."""
         s = np.ascontiguousarray(cam.state if isinstance(cam, Camera) else cam, np.float32)

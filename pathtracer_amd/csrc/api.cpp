@@ -115,7 +115,6 @@ struct PtHandle {
   bool haveScene = false, haveCamera = false;
   Camera cam{};
   FlatScene flat; LightTable lights; Bvh bvh;
-  WideBvh wide; bool useWide = false;    // the eight-wide form of bvh, when the scene is traversed from global memory
   std::string bvhNote;          // why the GPU builder was not used although asked for (empty otherwise)
   DevBuf dNodes, dTris, dNrm, dMats, dLights, dLightFirst, dLightCount, dLightArea;
   DevScene dsc{};
@@ -272,15 +271,7 @@ void uploadScene(PtHandle* h) {
   {
     // a scene that will be traversed from global memory gets its node pairs laid out by cache line
     const size_t lds = ((size_t)2 * h->bvh.numNodes + (size_t)3 * h->bvh.triOrder.size()) * 16;
-    const bool global = (f & PT_FLAG_NO_LDS_SCENE) || lds > 156 * 1024;
-    // ... as nodes of up to eight children, one cache line each; where that tree cannot be used (bvh.h: buildWide),
-    // or is not wanted, the sibling pairs are laid out by cache line instead
-    h->useWide = false; h->wide = WideBvh();
-    if (global && !(f & PT_FLAG_NO_WIDE_NODES)) {
-      h->useWide = buildWide(h->bvh, h->wide);
-      if (h->useWide) h->st.bvhBuildSeconds += h->wide.buildSeconds;
-    }
-    if (global && !h->useWide && !(f & PT_FLAG_NO_TREELETS)) {
+    if (((f & PT_FLAG_NO_LDS_SCENE) || lds > 156 * 1024) && !(f & PT_FLAG_NO_TREELETS)) {
       const auto t0 = std::chrono::steady_clock::now();
       treeletLayout(h->bvh);
       h->st.bvhBuildSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -324,7 +315,6 @@ void uploadScene(PtHandle* h) {
   DevScene& d = h->dsc;
   d.ldsBytes = (!(h->cfg.flags & PT_FLAG_NO_LDS_SCENE) && ldsNeed <= 156 * 1024) ? (uint32_t)ldsNeed : 0;
   h->st.sceneInLds = d.ldsBytes ? 1 : 0;
-  h->st.numWideNodes = h->useWide ? h->wide.numNodes : 0; h->st.wideDepth = h->useWide ? h->wide.depth : 0;
   if (h->cfg.device < 0) { h->haveScene = true; return; }
   auto up = [&](DevBuf& b, const void* src, size_t bytes) {
     b.alloc(bytes);
@@ -332,11 +322,7 @@ void uploadScene(PtHandle* h) {
   };
   HIPCHECK(hipStreamSynchronize(h->stream));
   if (d.ldsBytes) up(h->dNodes, bvh.nodes.data(), bvh.nodes.size() * 4);
-  else if (h->useWide) {   // traversal from global memory, eight-wide nodes
-    if (h->wide.nodes.empty()) h->dNodes.alloc(128);             // the root is a leaf
-    else up(h->dNodes, h->wide.nodes.data(), h->wide.nodes.size() * 4);
-    for (int k = 0; k < 3; k++) { d.qBase[k] = h->wide.maxAbs[k]; d.qScale[k] = 0.0f; }
-  } else {                 // traversal from global memory reads the 16-byte quantised nodes
+  else {                   // traversal from global memory reads the 16-byte quantised nodes
     std::vector<uint32_t> q((size_t)std::max(1u, bvh.numNodes) * 4, 0u);
     quantizeNodes(bvh.nodes.data(), bvh.numNodes, q.data(), d.qBase, d.qScale);
     up(h->dNodes, q.data(), q.size() * 4);
@@ -352,18 +338,16 @@ void uploadScene(PtHandle* h) {
   up(h->dLightCount, lc.data(), lc.size() * 4);
   up(h->dLightArea, la.data(), la.size() * 4);
 
-  d.nodes = d.ldsBytes ? h->dNodes.as<float4>() : nullptr;
-  d.qnodes = d.ldsBytes || h->useWide ? nullptr : h->dNodes.as<uint4>();
-  d.wnodes = !d.ldsBytes && h->useWide ? h->dNodes.as<uint4>() : nullptr;
+  d.nodes = d.ldsBytes ? h->dNodes.as<float4>() : nullptr; d.qnodes = d.ldsBytes ? nullptr : h->dNodes.as<uint4>();
   d.tris = h->dTris.as<float4>(); d.nrm = h->dNrm.as<float4>();
   d.mats = h->dMats.as<float4>(); d.lights = h->dLights.as<float>();
   d.lightFirst = h->dLightFirst.as<uint32_t>(); d.lightCount = h->dLightCount.as<uint32_t>();
   d.lightArea = h->dLightArea.as<float>();
-  d.numNodes = bvh.numNodes; d.numTris = NT; d.numOrigTris = T; d.rootRef = d.wnodes ? h->wide.rootRef : bvh.rootRef;
+  d.numNodes = bvh.numNodes; d.numTris = NT; d.numOrigTris = T; d.rootRef = bvh.rootRef;
   d.numLightGroups = (uint32_t)lt.numGroups(); d.numMats = (uint32_t)fs.mats.size(); d.numLightTris = (uint32_t)lt.tris.size();
   for (int k = 0; k < 3; k++) { h->box.mn[k] = bvh.nodes[k]; h->box.mx[k] = bvh.nodes[4 + k]; }   // node 0 = root
   h->haveScene = true; h->sceneGeneration++;
-  h->st.sceneBytes = (d.wnodes ? (uint64_t)h->wide.numNodes * 128 : (uint64_t)bvh.numNodes * (d.ldsBytes ? 32 : 16)) + (uint64_t)NT * 48;
+  h->st.sceneBytes = (uint64_t)bvh.numNodes * (d.ldsBytes ? 32 : 16) + (uint64_t)NT * 48;
   h->st.numTriangles = T; h->st.numNodes = bvh.numNodes; h->st.bvhDepth = bvh.depth;
   h->st.numLightGroups = d.numLightGroups; h->st.sceneInLds = d.ldsBytes ? 1 : 0;
 }
@@ -788,7 +772,7 @@ int ptgpu_set_config(PtHandle* h, const PtConfig* cfg) {
     if (c.device != h->cfg.device || c.width != h->cfg.width || c.height != h->cfg.height || c.batchSlots != h->cfg.batchSlots)
       fail(PT_E_INVALID, "device, width, height and batchSlots are fixed at ptgpu_create");
     bool rebuild = c.maxLeafTris != h->cfg.maxLeafTris ||
-                   ((c.flags ^ h->cfg.flags) & (PT_FLAG_NO_LDS_SCENE | PT_FLAG_GPU_BVH | PT_FLAG_HOST_BVH | PT_FLAG_NO_TREELETS | PT_FLAG_NO_WIDE_NODES));
+                   ((c.flags ^ h->cfg.flags) & (PT_FLAG_NO_LDS_SCENE | PT_FLAG_GPU_BVH | PT_FLAG_HOST_BVH | PT_FLAG_NO_TREELETS));
     if ((c.flags ^ h->cfg.flags) & PT_FLAG_NO_COVERAGE_MASK) h->maskDirty = true;
     h->cfg = c;
     if (rebuild && h->haveScene) { if (h->cfg.device >= 0) useDevice(h); uploadScene(h); }
@@ -851,36 +835,13 @@ int ptgpu_get_bvh(PtHandle* h, float* nodes8, uint32_t* triOrder) {
   return guarded([&]() {
     if (!h) fail(PT_E_INVALID, "null handle");
     if (!h->haveScene) fail(PT_E_STATE, "no scene");
-    if (nodes8 && h->dsc.ldsBytes == 0 && !h->useWide) {       // the boxes the kernels traverse: on the grid
+    if (nodes8 && h->dsc.ldsBytes == 0) {       // the boxes the kernels traverse: on the grid
       std::vector<uint32_t> q((size_t)std::max(1u, h->bvh.numNodes) * 4, 0u);
       float base[3], scale[3];
       quantizeNodes(h->bvh.nodes.data(), h->bvh.numNodes, q.data(), base, scale);
       dequantizeNodes(q.data(), h->bvh.numNodes, base, scale, nodes8);
     } else if (nodes8) std::memcpy(nodes8, h->bvh.nodes.data(), h->bvh.nodes.size() * 4);
     if (triOrder) std::memcpy(triOrder, h->bvh.triOrder.data(), h->bvh.triOrder.size() * 4);
-  });
-}
-
-int ptgpu_get_wide_nodes(PtHandle* h, uint32_t* nodes32, float* childBoxes48) {
-  return guarded([&]() {
-    if (!h) fail(PT_E_INVALID, "null handle");
-    if (!h->haveScene) fail(PT_E_STATE, "no scene");
-    if (!h->useWide) fail(PT_E_STATE, "the scene has no eight-wide tree (it is traversed from LDS, or PT_FLAG_NO_WIDE_NODES)");
-    if (nodes32 && !h->wide.nodes.empty()) std::memcpy(nodes32, h->wide.nodes.data(), h->wide.nodes.size() * 4);
-    if (childBoxes48)
-      for (uint32_t n = 0; n < h->wide.numNodes; n++) {
-        double b[WIDE_CHILDREN][6];
-        wideChildBoxes(&h->wide.nodes[(size_t)n * WIDE_WORDS], b);
-        // rounded towards the inside of the interval a test would allow: down for maxima, up for minima would hide a
-        // violation, so the minimum is rounded up and the maximum down only where the double is not a float already
-        for (uint32_t c = 0; c < WIDE_CHILDREN; c++)
-          for (int k = 0; k < 6; k++) {
-            float f = (float)b[c][k];
-            if (k < 3 && (double)f < b[c][k]) f = std::nextafterf(f, INFINITY);
-            if (k >= 3 && (double)f > b[c][k]) f = std::nextafterf(f, -INFINITY);
-            childBoxes48[((size_t)n * WIDE_CHILDREN + c) * 6 + k] = f;
-          }
-      }
   });
 }
 

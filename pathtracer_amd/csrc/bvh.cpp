@@ -243,97 +243,6 @@ void quantizeNodes(const float* nodes, uint32_t numNodes, uint32_t* out, float q
   }
 }
 
-bool buildWide(const Bvh& b, WideBvh& out) {
-  const auto t0 = std::chrono::steady_clock::now();
-  constexpr uint32_t NONE = 0xFFFFFFFFu;
-  auto refOf = [&](uint32_t node) { uint32_t r; std::memcpy(&r, &b.nodes[(size_t)node * 8 + 3], 4); return r; };
-  auto internal = [](uint32_t ref) { return (ref >> BVH_COUNT_SHIFT) == 0; };
-  auto halfArea = [&](uint32_t node) {
-    const float* p = &b.nodes[(size_t)node * 8];
-    const double dx = (double)p[4] - p[0], dy = (double)p[5] - p[1], dz = (double)p[6] - p[2];
-    return dx * dy + dy * dz + dz * dx;
-  };
-  WideBvh w;
-  w.rootRef = b.rootRef;
-  if (!internal(b.rootRef)) { w.buildSeconds = 0; out = std::move(w); return true; }      // the root is a leaf: no node at all
-  struct Item { uint32_t pair, wide, depth; };
-  std::vector<Item> todo; todo.push_back(Item{b.rootRef & BVH_INDEX_MASK, 0, 1});
-  w.nodes.assign(WIDE_WORDS, 0u); w.numNodes = 1; w.rootRef = 0;
-  w.nodes.reserve((size_t)b.numNodes / 5 * WIDE_WORDS + WIDE_WORDS);
-  while (!todo.empty()) {
-    const Item it = todo.back(); todo.pop_back();
-    w.depth = std::max(w.depth, it.depth);
-    uint32_t kids[WIDE_CHILDREN], n = 2;
-    kids[0] = 2 * it.pair; kids[1] = 2 * it.pair + 1;
-    while (n < WIDE_CHILDREN) {
-      int best = -1; double bestArea = -1.0;
-      for (uint32_t k = 0; k < n; k++)
-        if (internal(refOf(kids[k]))) { const double a = halfArea(kids[k]); if (a > bestArea) { bestArea = a; best = (int)k; } }
-      if (best < 0) break;
-      const uint32_t p = refOf(kids[best]) & BVH_INDEX_MASK;
-      kids[best] = 2 * p; kids[n++] = 2 * p + 1;
-    }
-    uint32_t node[WIDE_WORDS] = {0};
-    for (int k = 0; k < 3; k++) {
-      float org = FLT_MAX; double hi = -DBL_MAX;
-      for (uint32_t c = 0; c < n; c++) { org = std::min(org, b.nodes[(size_t)kids[c] * 8 + k]); hi = std::max(hi, (double)b.nodes[(size_t)kids[c] * 8 + 4 + k]); }
-      const double ext = hi - (double)org;
-      if (!std::isfinite(ext)) return false;
-      int e = 1;
-      if (ext > 0.0) { e = (int)std::ceil(std::log2(ext / 255.0)) + 127; e = std::max(e, 1); while (e <= 254 && std::ldexp(255.0, e - 127) < ext) e++; }
-      if (e > 254) return false;
-      const double cell = std::ldexp(1.0, e - 127);
-      std::memcpy(&node[k], &org, 4);
-      node[3] |= (uint32_t)e << (8 * k);
-      w.maxAbs[k] = std::max(w.maxAbs[k], std::fabs(org));
-      for (uint32_t c = 0; c < WIDE_CHILDREN; c++) {
-        long qlo = 255, qhi = 0;                                             // no child: never looked at (its reference says so)
-        if (c < n) {
-          const double mn = b.nodes[(size_t)kids[c] * 8 + k], mx = b.nodes[(size_t)kids[c] * 8 + 4 + k];
-          qlo = (long)std::floor((mn - (double)org) / cell); qhi = (long)std::ceil((mx - (double)org) / cell);
-          qlo = std::min(std::max(qlo, 0l), 255l); qhi = std::min(std::max(qhi, 0l), 255l);
-          while (qlo > 0 && !((double)org + (double)qlo * cell <= mn)) qlo--;           // exact in double
-          while (qhi < 255 && !((double)org + (double)qhi * cell >= mx)) qhi++;
-        }
-        const uint32_t half = c >> 2, sh = (c & 3u) * 8;
-        node[4 + 6 * half + k] |= (uint32_t)qlo << sh;
-        node[4 + 6 * half + 3 + k] |= (uint32_t)qhi << sh;
-      }
-    }
-    for (uint32_t c = 0; c < WIDE_CHILDREN; c++) {
-      uint32_t ref = NONE;
-      if (c < n) {
-        ref = refOf(kids[c]);
-        if (internal(ref)) {
-          const uint32_t idx = w.numNodes++;
-          if (idx >= (1u << BVH_COUNT_SHIFT)) return false;
-          w.nodes.resize((size_t)w.numNodes * WIDE_WORDS, 0u);
-          todo.push_back(Item{ref & BVH_INDEX_MASK, idx, it.depth + 1});
-          ref = idx;
-        }
-      }
-      node[16 + c] = ref;
-    }
-    std::memcpy(&w.nodes[(size_t)it.wide * WIDE_WORDS], node, sizeof(node));
-  }
-  if ((WIDE_CHILDREN - 1) * w.depth + 1 > WIDE_STACK) return false;
-  w.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  out = std::move(w);
-  return true;
-}
-
-void wideChildBoxes(const uint32_t* node, double out[WIDE_CHILDREN][6]) {
-  for (int k = 0; k < 3; k++) {
-    float org; std::memcpy(&org, &node[k], 4);
-    const double cell = std::ldexp(1.0, (int)((node[3] >> (8 * k)) & 0xFFu) - 127);
-    for (uint32_t c = 0; c < WIDE_CHILDREN; c++) {
-      const uint32_t half = c >> 2, sh = (c & 3u) * 8;
-      out[c][k] = (double)org + (double)((node[4 + 6 * half + k] >> sh) & 0xFFu) * cell;
-      out[c][3 + k] = (double)org + (double)((node[4 + 6 * half + 3 + k] >> sh) & 0xFFu) * cell;
-    }
-  }
-}
-
 void dequantizeNodes(const uint32_t* q, uint32_t numNodes, const float qBase[3], const float qScale[3], float* nodes) {
   for (uint32_t n = 0; n < numNodes; n++) {
     const uint32_t* w = q + (size_t)n * 4; float* p = nodes + (size_t)n * 8;

@@ -39,32 +39,6 @@ void dequantizeNodes(const uint32_t* q, uint32_t numNodes, const float qBase[3],
 // Changes only where pairs lie and the references between them: the tree, and so every traversal result, is the same.
 void treeletLayout(Bvh& bvh);
 
-// The tree for traversal from global memory as nodes of up to eight children, one 128-byte cache line each: every
-// step fetches one line and decides eight boxes, so a ray takes a third of the dependent memory round trips and
-// touches about half the lines the sibling pairs cost it.  Built by pulling grandchildren up into their grandparent
-// (always the child with the largest surface first) until a node has eight children or only leaves.  Leaves are the
-// binary tree's leaves: the references of leaf children and the triangle order do not change.
-// A node is 32 words:
-//   0..2   origin (float bits): the minimum corner of the union of the child boxes
-//   3      ex | ey << 8 | ez << 16: biased binary exponents, cell size of axis k = 2^(e_k - 127)
-//   4..15  child boxes on that 8-bit grid, rounded outwards.  Children 0..3: words 4..9 = lo.x lo.y lo.z hi.x hi.y hi.z,
-//          child c in byte c of each word; children 4..7 likewise in words 10..15.  plane = origin + q * cell
-//   16..23 child references as in the binary tree (count << 28 | first triangle, or the index of a wide node);
-//          0xFFFFFFFF = no child
-//   24..31 unused
-constexpr uint32_t WIDE_WORDS = 32, WIDE_CHILDREN = 8;
-constexpr uint32_t WIDE_STACK = 128;        // entries of the kernels' stack for this tree: 7 per level + 1
-struct WideBvh {
-  std::vector<uint32_t> nodes;       // numNodes x WIDE_WORDS
-  uint32_t numNodes = 0, rootRef = 0, depth = 0;
-  float maxAbs[3] = {0, 0, 0};       // largest |origin coordinate| per axis (the rays' rounding slack is scaled by it)
-  double buildSeconds = 0;
-};
-// False (out untouched) when the tree cannot be used: deeper than the stack allows or an extent beyond float exponents.
-bool buildWide(const Bvh& bvh, WideBvh& out);
-// The boxes a wide node's children stand for: out = 8 x (min.xyz, max.xyz) floats; an absent child gives an inverted box.
-void wideChildBoxes(const uint32_t* node, double out[WIDE_CHILDREN][6]);
-
 // v = T x 9 floats (v0, v1, v2).  Binned-SAH top-down build, leaves of at most maxLeaf triangles.  triCost: cost of a
 // triangle test relative to a step (one sibling pair): below 1 the tree gets fewer nodes and fuller leaves.
 void buildBvh(const float* v, uint32_t T, uint32_t maxLeaf, Bvh& out, float triCost = 1.0f);

@@ -32,8 +32,6 @@ struct DevScene {
   const uint4* qnodes;        // the same tree for traversal from global memory (ldsBytes == 0), 16 B per node: box
                               // planes on a 16-bit grid over the root box, x: min | max << 16, y, z likewise, w: ref.
                               // plane = qBase + q * qScale, rounded outwards: the boxes only grow
-  const uint4* wnodes;        // or, instead of qnodes, the same tree as nodes of up to eight children, 128 B each (bvh.h:
-                              // WideBvh): rootRef and the references of internal children index this array
   const float4* tris;         // 3 x float4 per leaf-order triangle: (v0, origId) (v2-v0, 0) (v1-v0, 0)
   const float4* nrm;          // 3 x float4 per ORIGINAL triangle: (n0, matIdx) (n1, 0) (n2, 0)
   const float4* mats;         // (emissive, r, g, b)                                   rendering.d:33-37
@@ -43,7 +41,7 @@ struct DevScene {
   const float* lightArea;     // g_totalLightSourceArea
   uint32_t numNodes, numTris, numOrigTris, rootRef, numLightGroups, numMats, numLightTris;
   uint32_t ldsBytes;          // 0 => traverse from global memory
-  float qBase[3], qScale[3];  // qnodes: the grid.  wnodes: qBase = largest |node origin| per axis, qScale unused
+  float qBase[3], qScale[3];
 };
 
 // The root box of the BVH.  A view ray that misses it cannot hit anything; raygen answers it without a traversal.

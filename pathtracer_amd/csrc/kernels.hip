@@ -180,11 +180,6 @@ struct Hit { float t, u, v; uint32_t tri; bool front; };
 // leaves room.  Besides 64 VGPRs this bounds the scalar registers: with more than 80 of them a SIMD holds only 7
 // waves, and a second 16-wave workgroup no longer fits on the CU.
 #define PT_TRAVERSAL_BOUNDS __launch_bounds__(1024, 8)
-// ... and with the scene in global memory (workgroups of 512 threads, no LDS to share) for PT_GLOBAL_WAVES waves per SIMD
-#ifndef PT_GLOBAL_WAVES
-#define PT_GLOBAL_WAVES 8
-#endif
-#define PT_TRAVERSAL_BOUNDS_FOR(LDSS) __launch_bounds__(1024, (LDSS) ? 8 : PT_GLOBAL_WAVES)
 
 // One triangle of a leaf: the two-sided Moeller-Trumbore test in the fixed evaluation order of pt_math.h.
 // ANY: returns true when the hit is accepted (Scene.hitsNothing stops there).  Otherwise updates the closest
@@ -279,63 +274,6 @@ __device__ __forceinline__ uint32_t stepDown(const DevScene& sc, const RayInv& r
   if (sp == 0) return PT_NONE;
   return popRef(stack, sp);
 }
-// One step down the eight-wide tree (bvh.h: WideBvh): one 128-byte node, eight box tests.  The ray is moved into the
-// node's frame -- plane = origin + q * 2^e, so the reciprocal direction is scaled by the (power of two, hence exact)
-// cell size and the origin goes into the addends with one fma per plane side and axis; the rounding of that fma is
-// covered by the ray's slack, which is scaled by the largest node origin of the scene (DevScene::qBase) -- and the
-// children are tested on their 8-bit planes, one byte-to-float conversion each.  Returns the nearest child that is hit;
-// the other hit children are pushed (in child order: only the first descent is ordered by distance).
-template <bool UNBOUNDED>
-__device__ __forceinline__ uint32_t stepDownWide(const DevScene& sc, const RayInv& ri, float tmax, uint32_t ref, uint32_t* stack, int& sp) {
-  const uint4* n = sc.wnodes + (size_t)ref * (WIDE_WORDS / 4);
-  const uint4 hd = n[0], qa = n[1], qb = n[2], qc = n[3], ra = n[4], rb = n[5];
-  RayInv r;
-  r.ix = ri.ix * u2f((hd.w & 0xFFu) << 23); r.iy = ri.iy * u2f((hd.w & 0xFF00u) << 15); r.iz = ri.iz * u2f((hd.w & 0xFF0000u) << 7);
-  r.a0x = fmaf(u2f(hd.x), ri.ix, ri.a0x); r.a1x = fmaf(u2f(hd.x), ri.ix, ri.a1x);
-  r.a0y = fmaf(u2f(hd.y), ri.iy, ri.a0y); r.a1y = fmaf(u2f(hd.y), ri.iy, ri.a1y);
-  r.a0z = fmaf(u2f(hd.z), ri.iz, ri.a0z); r.a1z = fmaf(u2f(hd.z), ri.iz, ri.a1z);
-  // words 4..9: children 0..3 (lo.x lo.y lo.z hi.x hi.y hi.z, a byte per child), words 10..15: children 4..7
-  const uint32_t q[12] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y, qc.z, qc.w};
-  const uint32_t refs[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
-  uint32_t nearRef = PT_NONE; float best = PT_FLT_MAX;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const int w = 6 * (k >> 2), sh = (k & 3) * 8;
-    float tn;
-    const bool hk = slab<-1, UNBOUNDED>(r, (float)((q[w] >> sh) & 0xFFu), (float)((q[w + 1] >> sh) & 0xFFu), (float)((q[w + 2] >> sh) & 0xFFu),
-                                        (float)((q[w + 3] >> sh) & 0xFFu), (float)((q[w + 4] >> sh) & 0xFFu), (float)((q[w + 5] >> sh) & 0xFFu),
-                                        tmax, tn) && refs[k] != PT_NONE;
-    const bool closer = hk && tn < best;
-    const uint32_t toPush = closer ? nearRef : refs[k];
-    if (hk && toPush != PT_NONE) stack[sp++] = toPush;
-    if (closer) { nearRef = refs[k]; best = tn; }
-  }
-  if (nearRef != PT_NONE) return nearRef;
-  if (sp == 0) return PT_NONE;
-  return popRef(stack, sp);
-}
-// Step down the tree a traversal loop was compiled for.  (Which tree a scene in global memory has is decided once per
-// ray, outside the loop -- traverse, advanceTrav: with the choice inside the step both node formats are live in the
-// loop and the binary tree's loop, at 64 registers, spills three times as much and runs 11 % slower.)
-template <bool LDSS, int OCT, bool UNBOUNDED, bool WIDE>
-__device__ __forceinline__ uint32_t stepAny(const DevScene& sc, const RayInv& ri, float tmax, uint32_t ref, uint32_t* stack, int& sp) {
-  static_assert(!(LDSS && WIDE), "the eight-wide tree is for scenes in global memory");
-  if constexpr (WIDE) return stepDownWide<UNBOUNDED>(sc, ri, tmax, ref, stack, sp);
-  else return stepDown<LDSS, OCT, UNBOUNDED>(sc, ri, tmax, ref, stack, sp);
-}
-// The ray as the box tests of the scene's tree want it.
-template <bool LDSS>
-__device__ __forceinline__ RayInv rayForTree(const DevScene& sc, V3 o, V3 d) {
-  RayInv ri = makeRayInv(o, d, LDSS ? v3(0, 0, 0) : v3(sc.qBase[0], sc.qBase[1], sc.qBase[2]));
-  if constexpr (!LDSS) {
-    if (!sc.wnodes) {        // box planes come as grid coordinates q: plane = qBase + q * qScale
-      ri.a0x = fmaf(sc.qBase[0], ri.ix, ri.a0x); ri.a1x = fmaf(sc.qBase[0], ri.ix, ri.a1x); ri.ix = sc.qScale[0] * ri.ix;
-      ri.a0y = fmaf(sc.qBase[1], ri.iy, ri.a0y); ri.a1y = fmaf(sc.qBase[1], ri.iy, ri.a1y); ri.iy = sc.qScale[1] * ri.iy;
-      ri.a0z = fmaf(sc.qBase[2], ri.iz, ri.a0z); ri.a1z = fmaf(sc.qBase[2], ri.iz, ri.a1z); ri.iz = sc.qScale[2] * ri.iz;
-    }
-  }
-  return ri;
-}
 __device__ __forceinline__ bool isInternal(uint32_t ref) { return (ref >> BVH_COUNT_SHIFT) == 0; }
 __device__ __forceinline__ bool isLeaf(uint32_t ref) { return (ref >> BVH_COUNT_SHIFT) != 0 && ref != PT_NONE; }
 
@@ -349,12 +287,12 @@ __device__ __forceinline__ bool isLeaf(uint32_t ref) { return (ref >> BVH_COUNT_
 // ray do not change the result (the closest hit does not depend on the order in which leaves are visited).
 // Measured: with the scene in LDS the bookkeeping costs more instructions than the better lane utilisation saves
 // (7-10 % slower); with the scene in HBM, where a step is a memory round trip, it is 25-35 % faster.
-template <bool ANY, bool LDSS, bool COUNT, int OCT, bool BOTH = false, bool WIDE = false>
+template <bool ANY, bool LDSS, bool COUNT, int OCT, bool BOTH = false>
 __device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri, V3 o, V3 d, float eps, Hit& h, uint32_t& cN, uint32_t& cT) {
   constexpr bool POSTPONE = !LDSS && !COUNT;
   h.t = PT_FLT_MAX; h.u = 0.0f; h.v = 0.0f; h.tri = 0xFFFFFFFFu; h.front = true;
   bool found = false;
-  uint32_t stack[LDSS ? 64 : WIDE_STACK];
+  uint32_t stack[64];
   int sp = 0;
   uint32_t ref = sc.rootRef;
   if constexpr (!POSTPONE) {
@@ -375,13 +313,10 @@ __device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri
           if (!in) cN += 1;                              // slots a lane spends waiting at a leaf (steps taken: the normal counting build)
           if (__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) == 0) cT += 64;
         }
-        if (in) ref = stepAny<LDSS, OCT, ANY, WIDE>(sc, ri, h.t, ref, stack, sp);
+        if (in) ref = stepDown<LDSS, OCT, ANY>(sc, ri, h.t, ref, stack, sp);
       }
 #else
-      while (isInternal(ref)) {
-        if (COUNT && !PT_STAMP_ON) cN += WIDE ? 8u : 2u;
-        ref = stepAny<LDSS, OCT, ANY, WIDE>(sc, ri, h.t, ref, stack, sp);
-      }
+      while (isInternal(ref)) { if (COUNT && !PT_STAMP_ON) cN += 2; ref = stepDown<LDSS, OCT, ANY>(sc, ri, h.t, ref, stack, sp); }
 #endif
 #ifdef PT_STAMP
       unsigned long long t1 = __builtin_amdgcn_s_memtime(); if (COUNT) cN += (uint32_t)(t1 - t0);
@@ -403,7 +338,7 @@ __device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri
     if (isLeaf(ref)) { leaf = ref; ref = PT_NONE; }                        // the root is a leaf
     for (;;) {
       while (isInternal(ref)) {
-        ref = stepAny<LDSS, OCT, ANY, WIDE>(sc, ri, h.t, ref, stack, sp);
+        ref = stepDown<LDSS, OCT, ANY>(sc, ri, h.t, ref, stack, sp);
         if (leaf == PT_NONE && isLeaf(ref)) { leaf = ref; ref = sp ? popRef(stack, sp) : PT_NONE; }
         if (!__any(leaf == PT_NONE && ref != PT_NONE)) break;
       }
@@ -426,8 +361,12 @@ __device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri
 // stand-alone variants, the general one.  Must be called with the lanes that have a ray active and no others.
 template <bool ANY, bool LDSS, bool COUNT, bool BY_OCTANT = !COUNT && !ANY, bool BOTH = false>
 __device__ __forceinline__ bool traverse(const DevScene& sc, V3 o, V3 d, float eps, Hit& h, uint32_t& cN, uint32_t& cT) {
-  RayInv ri = rayForTree<LDSS>(sc, o, d);
-  if constexpr (!LDSS) { if (sc.wnodes) return traverseOct<ANY, LDSS, COUNT, -1, BOTH, true>(sc, ri, o, d, eps, h, cN, cT); }
+  RayInv ri = makeRayInv(o, d, LDSS ? v3(0, 0, 0) : v3(sc.qBase[0], sc.qBase[1], sc.qBase[2]));
+  if constexpr (!LDSS) {     // box planes come as grid coordinates q: plane = qBase + q * qScale
+    ri.a0x = fmaf(sc.qBase[0], ri.ix, ri.a0x); ri.a1x = fmaf(sc.qBase[0], ri.ix, ri.a1x); ri.ix = sc.qScale[0] * ri.ix;
+    ri.a0y = fmaf(sc.qBase[1], ri.iy, ri.a0y); ri.a1y = fmaf(sc.qBase[1], ri.iy, ri.a1y); ri.iy = sc.qScale[1] * ri.iy;
+    ri.a0z = fmaf(sc.qBase[2], ri.iz, ri.a0z); ri.a1z = fmaf(sc.qBase[2], ri.iz, ri.a1z); ri.iz = sc.qScale[2] * ri.iz;
+  }
   if constexpr (BY_OCTANT) {
     uint32_t oct = octantOf(ri), o0 = __builtin_amdgcn_readfirstlane(oct);
     if (__all(oct == o0)) {
@@ -787,19 +726,23 @@ __device__ __forceinline__ void idleTrav(LaneTrav& t) {
 }
 __device__ __forceinline__ void startTrav(const DevScene& sc, LaneTrav& t, V3 o, V3 d) {
   t.o = o; t.d = d;
-  t.ri = rayForTree<false>(sc, o, d);
+  t.ri = makeRayInv(o, d, v3(sc.qBase[0], sc.qBase[1], sc.qBase[2]));
+  // box planes come as grid coordinates q: plane = qBase + q * qScale
+  t.ri.a0x = fmaf(sc.qBase[0], t.ri.ix, t.ri.a0x); t.ri.a1x = fmaf(sc.qBase[0], t.ri.ix, t.ri.a1x); t.ri.ix = sc.qScale[0] * t.ri.ix;
+  t.ri.a0y = fmaf(sc.qBase[1], t.ri.iy, t.ri.a0y); t.ri.a1y = fmaf(sc.qBase[1], t.ri.iy, t.ri.a1y); t.ri.iy = sc.qScale[1] * t.ri.iy;
+  t.ri.a0z = fmaf(sc.qBase[2], t.ri.iz, t.ri.a0z); t.ri.a1z = fmaf(sc.qBase[2], t.ri.iz, t.ri.a1z); t.ri.iz = sc.qScale[2] * t.ri.iz;
   t.h.t = PT_FLT_MAX; t.h.u = 0.0f; t.h.v = 0.0f; t.h.tri = 0xFFFFFFFFu; t.found = false;
   t.sp = 0; t.ref = sc.rootRef; t.leaf = PT_NONE;
   if (isLeaf(t.ref)) { t.leaf = t.ref; t.ref = PT_NONE; }
 }
 // Advances every lane's traversal until fewer than minBusy lanes are still at it (the postponed-leaf loop of
 // traverseOct, resumable; ANY: a lane stops at the first triangle it accepts).  Converged code.
-template <bool ANY, bool WIDE>
-__device__ __forceinline__ void advanceTravOn(const DevScene& sc, LaneTrav& t, uint32_t* stack, float eps, uint32_t minBusy) {
+template <bool ANY>
+__device__ __forceinline__ void advanceTrav(const DevScene& sc, LaneTrav& t, uint32_t* stack, float eps, uint32_t minBusy) {
   for (;;) {
     if ((uint32_t)__popcll(__ballot(t.busy())) < minBusy) break;
     while (isInternal(t.ref)) {
-      t.ref = stepAny<false, -1, ANY, WIDE>(sc, t.ri, t.h.t, t.ref, stack, t.sp);
+      t.ref = stepDown<false, -1, ANY>(sc, t.ri, t.h.t, t.ref, stack, t.sp);
       if (t.leaf == PT_NONE && isLeaf(t.ref)) { t.leaf = t.ref; t.ref = t.sp ? popRef(stack, t.sp) : PT_NONE; }
       if (!__any(t.leaf == PT_NONE && t.ref != PT_NONE)) break;
     }
@@ -812,11 +755,6 @@ __device__ __forceinline__ void advanceTravOn(const DevScene& sc, LaneTrav& t, u
       else if (isLeaf(t.ref)) { t.leaf = t.ref; t.ref = t.sp ? popRef(stack, t.sp) : PT_NONE; }
     }
   }
-}
-
-template <bool ANY>
-__device__ __forceinline__ void advanceTrav(const DevScene& sc, LaneTrav& t, uint32_t* stack, float eps, uint32_t minBusy) {
-  if (sc.wnodes) advanceTravOn<ANY, true>(sc, t, stack, eps, minBusy); else advanceTravOn<ANY, false>(sc, t, stack, eps, minBusy);
 }
 
 // The wave's share of a queue that is not handed to a lane yet, for the kernels whose lanes take a new entry when
@@ -874,7 +812,7 @@ __device__ __forceinline__ uint32_t appendToSegment(bool isHit, uint32_t seg, ui
 }
 
 template <bool PRIMARY>
-__global__ void PT_TRAVERSAL_BOUNDS_FOR(false) k_extend_refill(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, Wavefront wf) {
+__global__ void PT_TRAVERSAL_BOUNDS k_extend_refill(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, Wavefront wf) {
   __shared__ __align__(16) WorkPool pool;
   initPool(&pool);
   __syncthreads();
@@ -892,7 +830,7 @@ __global__ void PT_TRAVERSAL_BOUNDS_FOR(false) k_extend_refill(DevScene sc, DevC
   SegCursor cur; cur.seg = 0; cur.lo = 1; cur.hi = 0;
   bool hasRay = false; uint32_t slot = 0, jIn = 0; float carry = 0.0f;
   LaneTrav t; idleTrav(t);
-  uint32_t stack[WIDE_STACK];
+  uint32_t stack[64];
   WaveSupply sup;
   for (;;) {
     bool need = !hasRay;
@@ -1091,7 +1029,7 @@ template <bool LDST> struct ShadeTables {
 // At most one entry per lane slot and launch, so the read-modify-write of Lacc needs no atomics and the
 // per-lane order of additions (light 0, light 1, ..., sun, sky) is the launch order.
 template <bool LDSS, bool COUNT>
-__global__ void PT_TRAVERSAL_BOUNDS_FOR(LDSS) k_connect(DevScene sc, float eps, QMeta q, uint32_t segCap, const float4* __restrict__ shO,
+__global__ void PT_TRAVERSAL_BOUNDS k_connect(DevScene sc, float eps, QMeta q, uint32_t segCap, const float4* __restrict__ shO,
                                                   const float4* __restrict__ shD, const float4* __restrict__ shW,
                                                   uint32_t* taskCounter, float area, float4* __restrict__ Lacc,
                                                   uint32_t capSlots, uint32_t tag, unsigned long long* stats) {
@@ -1139,7 +1077,7 @@ __global__ void PT_TRAVERSAL_BOUNDS_FOR(LDSS) k_connect(DevScene sc, float eps, 
 // the kernel stores L = 0 + ... with the tag (see k_accumulate) without reading it.  Otherwise X = (BRDF * color
 // scaled by the chain's throughput, -) and L is read, added to and written back when a ray got through.
 template <bool LDSS, bool COUNT>
-__global__ void PT_TRAVERSAL_BOUNDS_FOR(LDSS) k_occluded(DevScene sc, float eps, V3 sunRadiance, V3 skyRadiance, int direct, QMeta q,
+__global__ void PT_TRAVERSAL_BOUNDS k_occluded(DevScene sc, float eps, V3 sunRadiance, V3 skyRadiance, int direct, QMeta q,
                                                    uint32_t segCap, const float4* __restrict__ shO, const float4* __restrict__ shD,
                                                    const float4* __restrict__ shW, const float4* __restrict__ shX,
                                                    uint32_t* taskCounter, float4* __restrict__ Lacc, uint32_t capSlots, uint32_t tag,
@@ -1738,7 +1676,7 @@ __global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_SAMPLE_WAVES) k_sample_t
 // back per vertex; L = 0 + sun + sky is stored once, with the tag.  Same operations per vertex as k_shade followed by
 // k_occluded (direct).
 template <bool LDSS>
-__global__ void PT_TRAVERSAL_BOUNDS_FOR(LDSS) k_shade_occluded(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, Wavefront wf) {
+__global__ void PT_TRAVERSAL_BOUNDS k_shade_occluded(DevScene sc, DevCfg cfg, PixMap pm, const float4* __restrict__ acc, Wavefront wf) {
   __shared__ __align__(16) WorkPool pool;
   initPool(&pool);
   stageScene<LDSS>(sc);
@@ -1977,7 +1915,6 @@ Geo traversalGeo(const LaunchCfg& lc, const DevScene& sc, uint64_t maxItems) {
     bs = 512; perCU = 4;
 #ifdef PT_DIAG_ENV
     if (const char* e = getenv("PT_DIAG_PERCU")) perCU = (uint32_t)atoi(e);      // diagnostic builds: occupancy of the global-memory kernels
-    if (const char* e = getenv("PT_DIAG_BS")) bs = (uint32_t)atoi(e);
 #endif
   }
   else { perCU = std::max(1u, ldsWorkgroupsPerCU(sc.ldsBytes)); bs = perCU == 8 ? 256 : perCU == 4 ? 512 : 1024; }

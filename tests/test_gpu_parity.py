@@ -135,15 +135,12 @@ def test_texcoord_trace_equals_oracle(require_gpu, name, lds, flats):
     assert len(pt.trace_tex(np.zeros((0, 6), np.float32))[0]) == 0
 
 
-@pytest.mark.parametrize('tree', ['wide', 'binary'])
-def test_scene_traversed_from_global_memory_gives_the_same_hits(require_gpu, tree, flats):
-    """PT_FLAG_NO_LDS_SCENE: the HBM/L2 variant of every traversal kernel against the LDS-staged one, with the
-    eight-wide nodes (default) and with the binary tree's 16-byte nodes (PT_FLAG_NO_WIDE_NODES)."""
+def test_scene_traversed_from_global_memory_gives_the_same_hits(require_gpu, flats):
+    """PT_FLAG_NO_LDS_SCENE: the HBM/L2 variant of every traversal kernel against the LDS-staged one."""
     name, W, H = 'teapot', 320, 180
     a = make_tracer(name, W, H)
-    b = make_tracer(name, W, H, flags=P.PT_FLAG_NO_LDS_SCENE | (P.PT_FLAG_NO_WIDE_NODES if tree == 'binary' else 0))
+    b = make_tracer(name, W, H, flags=P.PT_FLAG_NO_LDS_SCENE)
     assert a.stats().sceneInLds == 1 and b.stats().sceneInLds == 0
-    assert (b.stats().numWideNodes > 0) == (tree == 'wide')
     for x, y in zip(a.trace_primary(), b.trace_primary()):
         assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
     rays = random_rays(flats[name], 20000, 1)
@@ -158,13 +155,12 @@ def test_hits_do_not_depend_on_the_tree(require_gpu, leaf, flats):
     assert_hits_equal(pt.trace_primary(), ref)
 
 
-@pytest.mark.parametrize('tree', ['wide', 'binary'])
-def test_soup_scene_from_global_memory(require_gpu, tree):
+def test_soup_scene_from_global_memory(require_gpu):
     """200k-triangle soup (too large for LDS): closest hits and occlusion against the exhaustive oracle on a sample
     of camera rays and random interior rays."""
     fl = soup(200000, seed=0x5EED)
     W, H = 96, 54
-    pt = P.PathTracer(W, H, flags=P.PT_FLAG_NO_WIDE_NODES if tree == 'binary' else 0)
+    pt = P.PathTracer(W, H)
     pt.upload_scene(fl['v'], fl['n'], fl['mat_idx'], fl['materials'])
     cam = P.Camera(30.0, H / W).setTransform((250, 180, 160), (0, 0, 0), (0, 0, 1))
     pt.set_camera(cam)
@@ -289,7 +285,7 @@ def test_visit_counters_match_cpu_restatement_of_the_traversal(require_gpu, flat
     assert abs(st.trisClosest - n_tris) <= 1e-3 * n_tris
     # any-hit queries: children in storage order when the scene is in LDS, near child first when it is not
     rays = random_rays(flats[name], 40000, 3)
-    for flags, order_rule in ((P.PT_FLAG_COUNT_VISITS, 2), (P.PT_FLAG_COUNT_VISITS | P.PT_FLAG_NO_LDS_SCENE | P.PT_FLAG_NO_WIDE_NODES, 1)):
+    for flags, order_rule in ((P.PT_FLAG_COUNT_VISITS, 2), (P.PT_FLAG_COUNT_VISITS | P.PT_FLAG_NO_LDS_SCENE, 1)):
         pa = make_tracer(name, W, H, flags=flags)
         nodes, order = pa.get_bvh()
         root = int(nodes[0, 3:4].view(np.uint32)[0])             # (the node pairs of a scene in global memory are laid out anew)
@@ -300,19 +296,16 @@ def test_visit_counters_match_cpu_restatement_of_the_traversal(require_gpu, flat
         assert abs(st.nodesAny - n_nodes) <= 1e-3 * n_nodes and abs(st.trisAny - n_tris) <= 1e-3 * n_tris
 
 
-@pytest.mark.parametrize('tree', ['wide', 'binary'])
 @pytest.mark.parametrize('extent,size,offset', [(1e4, 1e-2, 0.0), (5.0, 3.0, 1e5), (1e-3, 4e-4, 0.0), (100.0, 40.0, -3e3)])
-def test_quantised_nodes_on_extreme_scales(require_gpu, extent, size, offset, tree):
-    """Scenes traversed from global memory (eight-wide nodes with an 8-bit grid per node, or the binary tree on a 16-bit
-    grid over the root box) whose scale defeats naive rounding:
+def test_quantised_nodes_on_extreme_scales(require_gpu, extent, size, offset):
+    """Scenes traversed from global memory (16-bit box grid over the root box) whose scale defeats naive rounding:
     triangles far smaller than a grid cell, coordinates far from the origin (the grid-to-world map is evaluated in
     fp32), a scene of millimetre extent, triangles as large as the scene.  Hits must equal the exhaustive oracle's."""
     fl = soup(2500, seed=3, extent=extent, size=size)
     fl['v'] = (fl['v'] + np.float32(offset)).astype(np.float32)
-    pt = P.PathTracer(16, 16, flags=P.PT_FLAG_NO_LDS_SCENE | (P.PT_FLAG_NO_WIDE_NODES if tree == 'binary' else 0),
-                      eps=1e-5 if extent > 1 else 1e-12)
+    pt = P.PathTracer(16, 16, flags=P.PT_FLAG_NO_LDS_SCENE, eps=1e-5 if extent > 1 else 1e-12)
     pt.upload_scene(fl['v'], fl['n'], fl['mat_idx'], fl['materials'])
-    assert pt.stats().sceneInLds == 0 and (pt.stats().numWideNodes > 0) == (tree == 'wide')
+    assert pt.stats().sceneInLds == 0
     o = oracle_py.Oracle(fl, build_tree=False); o.configure(width=16, height=16, eps=1e-5 if extent > 1 else 1e-12)
     rays = random_rays(fl, 12000, 17)
     tri, t, u, v, _ = pt.trace(rays)

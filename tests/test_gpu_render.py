@@ -274,7 +274,7 @@ def test_full_size_properties(require_gpu):
     assert (is_sky | is_sun | (c.max(1) > 1)).all() and is_sky.mean() > 0.99
 
 
-@pytest.mark.parametrize('flags', [0, P.PT_FLAG_NO_LDS_SCENE, P.PT_FLAG_NO_LDS_SCENE | P.PT_FLAG_NO_WIDE_NODES])
+@pytest.mark.parametrize('flags', [0, P.PT_FLAG_NO_LDS_SCENE])
 @pytest.mark.parametrize('mode', [0, 1])
 def test_lights_and_sky_together_equal_oracle_with_same_streams(require_gpu, flags, mode):
     """A scene with a light group AND the sky: the light-sample kernel adds to a vertex's radiance first, the sun/sky
@@ -510,7 +510,7 @@ def test_wavefront_state_follows_the_path_the_scene_takes(require_gpu):
     pt.close()
 
 
-@pytest.mark.parametrize('flags', [0, P.PT_FLAG_NO_LDS_SCENE, P.PT_FLAG_NO_LDS_SCENE | P.PT_FLAG_NO_WIDE_NODES])
+@pytest.mark.parametrize('flags', [0, P.PT_FLAG_NO_LDS_SCENE])
 def test_traversal_kernel_that_shades_its_hits_equals_the_queued_path(require_gpu, flags):
     """Mode 0, sky, no light group, a scene too large for the shading kernel's LDS (the teapot): the kernel that traces
     the sun and sky rays shades the view-ray hits itself, from the hit queue.  Same bits and counters as shade followed

@@ -349,17 +349,14 @@ def test_texcoords_of_uploaded_scenes_default_to_zero_and_can_be_set():
     assert not pt.get_texcoords().any()
 
 
-BINARY = P.PT_FLAG_NO_LDS_SCENE | P.PT_FLAG_NO_WIDE_NODES      # a scene in global memory that keeps the binary tree
-
-
 @pytest.mark.parametrize('name', NAMES + ['soup'])
 def test_quantised_nodes_contain_their_boxes(name, flats):
-    """Scenes traversed from global memory as a binary tree get 16-byte nodes on a 16-bit grid over the root box: every box returned for
+    """Scenes traversed from global memory get 16-byte nodes on a 16-bit grid over the root box: every box returned for
     such a scene contains the float box of the same node, by no more than a few grid cells, and the tree is the same."""
     if name == 'soup':
-        fl = soup(3000, seed=11); a = host_tracer(flat=fl, flags=P.PT_FLAG_NO_TREELETS); b = host_tracer(flat=fl, flags=BINARY | P.PT_FLAG_NO_TREELETS)
+        fl = soup(3000, seed=11); a = host_tracer(flat=fl, flags=P.PT_FLAG_NO_TREELETS); b = host_tracer(flat=fl, flags=P.PT_FLAG_NO_LDS_SCENE | P.PT_FLAG_NO_TREELETS)
     else:
-        a = host_tracer(name); b = host_tracer(name, flags=BINARY | P.PT_FLAG_NO_TREELETS)
+        a = host_tracer(name); b = host_tracer(name, flags=P.PT_FLAG_NO_LDS_SCENE | P.PT_FLAG_NO_TREELETS)
     assert b.stats().sceneInLds == 0
     (na, oa), (nb, ob) = a.get_bvh(), b.get_bvh()
     assert np.array_equal(oa, ob) and np.array_equal(na[:, 3].view(np.uint32), nb[:, 3].view(np.uint32))
@@ -380,9 +377,9 @@ def test_cache_line_layout_of_the_node_pairs_keeps_the_tree(name, flats):
     and few slots are padding."""
     if name == 'soup':
         fl = soup(20000, seed=5)
-        a = host_tracer(flat=fl, flags=BINARY | P.PT_FLAG_NO_TREELETS); b = host_tracer(flat=fl, flags=BINARY)
+        a = host_tracer(flat=fl, flags=P.PT_FLAG_NO_LDS_SCENE | P.PT_FLAG_NO_TREELETS); b = host_tracer(flat=fl, flags=P.PT_FLAG_NO_LDS_SCENE)
     else:
-        a = host_tracer(name, flags=BINARY | P.PT_FLAG_NO_TREELETS); b = host_tracer(name, flags=BINARY)
+        a = host_tracer(name, flags=P.PT_FLAG_NO_LDS_SCENE | P.PT_FLAG_NO_TREELETS); b = host_tracer(name, flags=P.PT_FLAG_NO_LDS_SCENE)
     (na, oa), (nb, ob) = a.get_bvh(), b.get_bvh()
     assert np.array_equal(oa, ob)
     ra, rb = na[:, 3].view(np.uint32), nb[:, 3].view(np.uint32)
@@ -405,74 +402,3 @@ def test_cache_line_layout_of_the_node_pairs_keeps_the_tree(name, flats):
     unused = rb.reshape(-1, 2)[:, 0] == 0xFFFFFFFF
     assert int((~unused).sum()) == pairs + 1 and unused.mean() < 0.2
     assert same_line / pairs > 0.5                                   # at most 3 of 4: the first pair of a line comes from another
-
-
-@pytest.mark.parametrize('name', NAMES + ['soup', 'one', 'far', 'flat'])
-def test_eight_wide_nodes_hold_the_binary_tree(name, flats):
-    """Scenes traversed from global memory are walked as nodes of up to eight children on an 8-bit grid of the node
-    (bvh.h: buildWide).  Walked from the root in step with the binary tree: the children of a wide node are the
-    frontier of a subtree of the binary tree rooted at the matching pair (every leaf reference kept as it is, every
-    pair of the binary tree met exactly once), every child box contains the binary tree's float box, by no more than
-    two cells of the node's grid, and the grid spans at most 255 cells."""
-    if name in NAMES:
-        b = host_tracer(name, flags=P.PT_FLAG_NO_LDS_SCENE)
-    else:
-        fl = {'soup': lambda: soup(20000, seed=5), 'one': lambda: soup(1, seed=1), 'far': lambda: soup(3000, seed=2, extent=5.0, size=3.0),
-              'flat': lambda: soup(500, seed=4)}[name]()
-        if name == 'far': fl['v'] = (fl['v'] + np.float32(1e5)).astype(np.float32)
-        if name == 'flat': fl['v'][:, :, 2] = 0.25                      # every vertex in one plane: an axis of zero extent
-        if name == 'one': fl = dict(fl, v=fl['v'][:1], n=fl['n'][:1], mat_idx=fl['mat_idx'][:1])
-        b = host_tracer(flat=fl, flags=P.PT_FLAG_NO_LDS_SCENE)
-    st = b.stats()
-    assert st.sceneInLds == 0
-    nodes, order = b.get_bvh()
-    ref2 = nodes[:, 3].view(np.uint32)
-    if name == 'one':
-        assert st.numWideNodes == 0 and int(ref2[0]) >> 28 == 1           # the root is a leaf: nothing to widen
-        return
-    assert st.numWideNodes > 0 and 7 * st.wideDepth + 1 <= 128
-    wide, boxes = b.get_wide_nodes()
-    assert len(wide) == st.numWideNodes
-    # the binary tree's leaves, with the float boxes of their nodes
-    leafbox = {}
-    todo = [int(ref2[0])]
-    while todo:
-        p = todo.pop()
-        for node in (2 * p, 2 * p + 1):
-            r = int(ref2[node])
-            if r >> 28:
-                assert r not in leafbox; leafbox[r] = (nodes[node, 0:3].astype(np.float64), nodes[node, 4:7].astype(np.float64))
-            else: todo.append(r)
-    seen_wide = set(); seen_leaves = []
-    depth = [0]
-
-    def walk(w, level):
-        assert w not in seen_wide; seen_wide.add(w)
-        depth[0] = max(depth[0], level)
-        refs = wide[w, 16:24]
-        n = int((refs != 0xFFFFFFFF).sum())
-        assert 2 <= n <= 8 and (refs[n:] == 0xFFFFFFFF).all()
-        cell = np.array([2.0 ** (((int(wide[w, 3]) >> (8 * k)) & 0xFF) - 127) for k in range(3)])
-        org = wide[w, 0:3].view(np.float32).astype(np.float64)
-        lo_all = np.full(3, np.inf); hi_all = np.full(3, -np.inf)
-        for c in range(n):
-            r = int(refs[c])
-            if r >> 28:
-                seen_leaves.append(r); mn, mx = leafbox[r]
-            else:
-                mn, mx = walk(r, level + 1)
-            q = np.array([(int(wide[w, 4 + 6 * (c >> 2) + k]) >> (8 * (c & 3))) & 0xFF for k in range(6)])
-            assert (q[:3] <= q[3:]).all()
-            # the box the bytes stand for is the one the accessor reports, it contains everything below the child
-            # and is no looser than a cell and a rounding beyond it
-            assert np.allclose(boxes[w, c, 0:3], org + q[:3] * cell, rtol=1e-6, atol=0) and np.allclose(boxes[w, c, 3:6], org + q[3:] * cell, rtol=1e-6, atol=0)
-            lo, hi = org + q[:3] * cell, org + q[3:] * cell
-            assert (lo <= mn).all() and (hi >= mx).all(), (name, w, c)
-            assert ((mn - lo) <= 1.01 * cell).all() and ((hi - mx) <= 1.01 * cell).all(), (name, w, c)
-            lo_all = np.minimum(lo_all, mn); hi_all = np.maximum(hi_all, mx)
-        assert (org <= lo_all).all() and ((hi_all - org) <= 255 * cell).all()
-        return lo_all, hi_all
-
-    walk(0, 1)
-    assert len(seen_wide) == st.numWideNodes and depth[0] == st.wideDepth
-    assert sorted(seen_leaves) == sorted(leafbox)                   # every leaf of the binary tree, once
