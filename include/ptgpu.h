@@ -194,7 +194,7 @@ int ptgpu_synchronize(PtHandle* h);
  * the life of the process, and the call makes no hipMalloc / hipFree, creates no event and builds nothing on the
  * host.  The whole window is ONE batch: pixelCount * spp must fit the array for the handle's scene and configuration
  * (a scene whose samples are one launch each, i.e. up to 24 KB of nodes, triangles and shading tables, keeps no ray
- * queues: 1769472 samples in mode 0, 131072 in mode 1 with five chains; other scenes, mode 0: 655360 samples without
+ * queues: 1769472 samples in mode 0, 65536 in mode 1 with five chains; other scenes, mode 0: 655360 samples without
  * light groups, 458752 with one; mode 1 with five chains: 65536); a larger request fails with PT_E_INVALID and a message
  * that states the limit.  The view-ray masks are used when an earlier ptgpu_render built them for the current
  * camera, otherwise the rays are culled by the scene's bounding box (same image).  All calls on one GPU share the

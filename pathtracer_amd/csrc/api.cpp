@@ -120,7 +120,7 @@ struct PtHandle {
   DevScene dsc{};
   DevBuf accOwn; float4* acc = nullptr; uint64_t accBytes = 0;
   // wavefront buffers
-  DevBuf bSlotQ, bHitA, bHitB, bRayO, bRayD, bLacc, bThr, bRng, bShO, bShD, bShW, bShX, bCounters, bStats;
+  DevBuf bSlotQ, bHitA, bHitB, bRayO, bRayD, bLacc, bRng, bShO, bShD, bShW, bShX, bCounters, bStats;
   SceneBox box{};
   // coverage mask of the view rays (scene_host.h: buildCoverageMask); rebuilt when the scene or the camera changes
   DevBuf dMask, dSkyMask; bool maskDirty = true, maskUsable = false;
@@ -363,6 +363,8 @@ bool sceneFusable(const PtHandle* h) {
   const uint32_t tables = shadeTableBytes(h->dsc);
   if (!h->dsc.ldsBytes || !tables || h->dsc.ldsBytes + tables > PT_FUSE_LDS_BYTES) return false;
   const bool chains = c.mode == 1 && c.numIndirect > 0;
+  // which chains' first rays hit is kept in the top eight bits of the view-ray record's tag word
+  if (chains && (c.numIndirect > 8 || h->dsc.numMats >= 0xFFFFFFu)) return false;
   return chains || c.hasSky || (c.hasLights && h->dsc.numLightGroups);
 }
 
@@ -386,20 +388,23 @@ void ensureWavefront(PtHandle* h) {
   want = std::min<uint64_t>(want, frame * 256);
   uint32_t NI = c.mode == 1 ? c.numIndirect : 0;
   uint32_t lanes = 1 + NI;
+  // radiance records: one per path slot and one per chain and bounce round (kernels.h: Wavefront::Lacc)
+  const uint64_t recLanes = 1 + (uint64_t)NI * (c.maxDepth + 1);
   if (!c.batchSlots) {       // the default yields to the memory that is actually free (the caller may hold most of it)
     // decided once per shape of the wavefront state, not per render call
     if (h->wf.capSlots && h->wf.lanes == lanes && h->wfKinds == numKinds(h) && h->wfRounds == (c.mode == 1 ? c.maxDepth + 4 : 2) &&
         h->wfLean == lean) return;
     size_t freeB = 0, totalB = 0;
     HIPCHECK(hipMemGetInfo(&freeB, &totalB));
-    uint64_t perSlot = 16ull * lanes + (NI ? 24ull * lanes : 0) + (uint64_t)std::max(1u, NI) * (32 + (NI ? 32 : 0));
+    uint64_t perSlot = 16ull * recLanes + (NI ? 8ull * lanes : 0) + (uint64_t)std::max(1u, NI) * (32 + (NI ? 32 : 0));
     if (!lean) perSlot += 16 + (uint64_t)std::max(1u, NI) * (48ull * numKinds(h) + 16);
     uint64_t held = h->wf.capSlots ? (uint64_t)h->wf.capSlots * perSlot : 0;       // what this handle would give back
     while (want > gran && want * perSlot > (freeB + held) / 2) want /= 2;
   }
+  while (want > gran && want * recLanes > 0xFFFFFFFFull) want /= 2;          // records are indexed with 32 bits
   uint32_t capSlots = (uint32_t)std::min<uint64_t>(((want + gran - 1) / gran) * gran, 0x40000000ull);
   uint64_t capQueue = (uint64_t)capSlots * std::max(1u, NI);
-  if (capQueue > 0x7FFFFFFFull || (uint64_t)capSlots * lanes > 0xFFFFFFFFull) fail(PT_E_INVALID, "batchSlots * numIndirect too large");
+  if (capQueue > 0x7FFFFFFFull || (uint64_t)capSlots * recLanes > 0xFFFFFFFFull) fail(PT_E_INVALID, "batchSlots * numIndirect * (maxDepth + 1) too large");
   uint32_t kinds = numKinds(h), rounds = c.mode == 1 ? c.maxDepth + 4 : 2;
   Wavefront& w = h->wf;
   if (w.capSlots == capSlots && w.capQueue == (uint32_t)capQueue && w.lanes == lanes && h->wfKinds == kinds && h->wfRounds == rounds &&
@@ -411,10 +416,7 @@ void ensureWavefront(PtHandle* h) {
   // indirect rays only; as large as the hit arrays, so that the fused shading can use the two pairs alternately as the
   // hit queues of successive bounce rounds (kernels.h: Wavefront::hitOutA)
   h->bRayO.alloc(NI ? capHit * 16 : 16); h->bRayD.alloc(NI ? capHit * 16 : 16);
-  h->bLacc.alloc((uint64_t)lanes * capSlots * 16);
-  // chain records are recognised by the tag of the batch that wrote them: fresh memory must not hold one by chance
-  HIPCHECK(hipMemset(h->bLacc.p, 0, (uint64_t)lanes * capSlots * 16));
-  h->bThr.alloc(NI ? (uint64_t)lanes * capSlots * 16 : 16);
+  h->bLacc.alloc(recLanes * capSlots * 16);
   h->bRng.alloc(NI ? (uint64_t)lanes * capSlots * 8 : 16);
   h->bShO.alloc(lean ? 16 : (uint64_t)kinds * capQueue * 16);
   h->bShD.alloc(lean ? 16 : (uint64_t)kinds * capQueue * 16);
@@ -437,10 +439,11 @@ void ensureWavefront(PtHandle* h) {
   w.runPool = (h->cfg.flags & PT_FLAG_STATIC_RUNS) ? nullptr : w.taskCounters + PT_TASK_WORDS;
   w.slotQ = h->bSlotQ.as<float4>(); w.hitA = h->bHitA.as<float4>(); w.hitB = h->bHitB.as<float4>();
   w.rayO = h->bRayO.as<float4>(); w.rayD = h->bRayD.as<float4>();
-  w.Lacc = h->bLacc.as<float4>(); w.thr = h->bThr.as<float4>(); w.rng = h->bRng.as<uint2>();
+  w.Lacc = h->bLacc.as<float4>(); w.rng = h->bRng.as<uint2>();
   w.shO = h->bShO.as<float4>(); w.shD = h->bShD.as<float4>(); w.shW = h->bShW.as<float4>(); w.shX = h->bShX.as<float4>();
   w.stats = h->bStats.as<unsigned long long>();
   w.capSlots = capSlots; w.capQueue = (uint32_t)capQueue; w.capHit = (uint32_t)capHit; w.lanes = lanes;
+  w.chainStride = NI * capSlots; w.recRounds = c.maxDepth + 1;
   w.rayCap = NI ? (uint32_t)capHit : 0u; w.hitOutA = w.hitOutB = nullptr; w.fuse = 0; w.chainMask = 0;
   h->wfKinds = kinds; h->wfRounds = rounds; h->wfLean = lean;
 }
@@ -461,9 +464,6 @@ void launchShadowKinds(PtHandle* h, const LaunchCfg& lc, const DevCfg& dc, const
 // Where a batch keeps its state: the handle's own buffers (ensureWavefront) or the static scratch array.
 struct WfState { Wavefront wf; const QMeta* hostMetas; const QMeta* devMetas; ViewMasks masks; };
 
-// Tags of the batches of this process (Wavefront::tag): never zero, never repeated while a record could still hold one.
-std::atomic<uint32_t> g_batchTag{0};
-
 // Whether this batch runs the shading variant that traces the rays it spawns (kernels.h: Wavefront::fuse): scene and
 // shading tables small enough to share a shade workgroup's LDS and, for the chains, ray arrays as large as the hit arrays.
 uint32_t fuseBits(const PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, const Wavefront& wf) {
@@ -475,10 +475,9 @@ uint32_t fuseBits(const PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, cons
 
 void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, const WfState& ws) {
   Wavefront wf = ws.wf;
-  do { wf.tag = ++g_batchTag; } while (wf.tag == 0);
   wf.divCap = makeFastDiv(wf.capSlots); wf.round = 0;
   wf.fuse = fuseBits(h, dc, lc, wf);
-  wf.chainMask = wf.fuse && dc.mode == 1 && dc.numIndirect <= 8 && h->dsc.numMats < 0xFFFFFFu ? 1u : 0u;
+  wf.chainMask = wf.fuse && dc.mode == 1 ? 1u : 0u;          // (sceneFusable has made sure that the mask fits)
   const uint32_t perStage = 2 + PT_MAX_KINDS;
   const int kinds = (int)((dc.hasLights ? h->dsc.numLightGroups : 0) + (dc.hasSky ? 1 : 0));
   const QMeta* desc = ws.devMetas;
@@ -659,10 +658,6 @@ void renderPixels(PtHandle* h, PixMap base, uint64_t totalPix, uint32_t spp, con
     if (capturing) {
       hipGraph_t graph = nullptr;
       try {
-        // chain radiance records are told apart by the batch tag, which is fixed in a captured launch: clear the part
-        // of them this batch uses, so that a replay never meets its own tag from the replay before
-        for (uint32_t c = 1; c < ws.wf.lanes; c++)
-          HIPCHECK(hipMemsetAsync(ws.wf.Lacc + (size_t)c * ws.wf.capSlots, 0, (size_t)nslotsAll * 16, h->stream));
         h->noEvents = true;
         renderBatch(h, dc, lc, pm, ws);
         h->noEvents = false;
@@ -883,8 +878,8 @@ int ptgpu_render(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount, uint32_
 // in the scratch array (offsets in bytes, each a multiple of 256).
 namespace {
 struct NoAllocLayout {
-  size_t slotQ, hitA, hitB, rayO, rayD, Lacc, thr, rng, shO, shD, shW, shX, words, desc, total;
-  uint32_t capSlots, capQueue, capHit, lanes, kinds, rounds, rayCap;
+  size_t slotQ, hitA, hitB, rayO, rayD, Lacc, rng, shO, shD, shW, shX, words, desc, total;
+  uint32_t capSlots, capQueue, capHit, lanes, recLanes, kinds, rounds, rayCap;
   bool lean;
 };
 constexpr uint32_t PT_NOALLOC_GROUPS = 128;      // traversal workgroups per launch: bounds the hit queue's slack
@@ -893,7 +888,7 @@ NoAllocLayout layoutNoAlloc(const PtHandle* h, uint32_t capSlots) {
   const PtConfig& c = h->cfg;
   NoAllocLayout L{};
   const uint32_t NI = c.mode == 1 ? c.numIndirect : 0;
-  L.capSlots = capSlots; L.lanes = 1 + NI; L.kinds = numKinds(h); L.rounds = c.mode == 1 ? c.maxDepth + 4 : 2;
+  L.capSlots = capSlots; L.lanes = 1 + NI; L.recLanes = 1 + NI * (c.maxDepth + 1); L.kinds = numKinds(h); L.rounds = c.mode == 1 ? c.maxDepth + 4 : 2;
   // as ensureWavefront: a scene whose batches are whole-sample launches keeps no view-ray queue and no shadow queues,
   // and its ray arrays are as large as the hit arrays (the two pairs alternate between bounce rounds)
   L.lean = sceneFusable(h) && !(c.flags & PT_FLAG_QUEUED_VIEW_RAYS);
@@ -909,8 +904,7 @@ NoAllocLayout layoutNoAlloc(const PtHandle* h, uint32_t capSlots) {
   const uint64_t rayEntries = !NI ? 1 : L.lean ? capHit : capQueue;
   L.rayCap = NI && L.lean ? (uint32_t)capHit : 0u;
   L.rayO = piece(rayEntries * 16); L.rayD = piece(rayEntries * 16);
-  L.Lacc = piece((uint64_t)L.lanes * capSlots * 16);
-  L.thr = piece(NI ? (uint64_t)L.lanes * capSlots * 16 : 16);
+  L.Lacc = piece((uint64_t)L.recLanes * capSlots * 16);
   L.rng = piece(NI ? (uint64_t)L.lanes * capSlots * 8 : 16);
   const uint64_t sh = L.lean ? 16 : (uint64_t)L.kinds * capQueue * 16;
   L.shO = piece(sh); L.shD = piece(sh); L.shW = piece(sh); L.shX = piece(L.lean ? 16 : capQueue * 16);
@@ -955,10 +949,11 @@ int ptgpu_render_noalloc(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount,
     Wavefront& w = ws.wf;
     w.slotQ = (float4*)(base + L.slotQ); w.hitA = (float4*)(base + L.hitA); w.hitB = (float4*)(base + L.hitB);
     w.rayO = (float4*)(base + L.rayO); w.rayD = (float4*)(base + L.rayD); w.Lacc = (float4*)(base + L.Lacc);
-    w.thr = (float4*)(base + L.thr); w.rng = (uint2*)(base + L.rng);
+    w.rng = (uint2*)(base + L.rng);
     w.shO = (float4*)(base + L.shO); w.shD = (float4*)(base + L.shD); w.shW = (float4*)(base + L.shW); w.shX = (float4*)(base + L.shX);
     w.stats = h->bStats.as<unsigned long long>();
     w.capSlots = L.capSlots; w.capQueue = L.capQueue; w.capHit = L.capHit; w.lanes = L.lanes; w.rayCap = L.rayCap;
+    w.chainStride = (L.lanes - 1) * L.capSlots; w.recRounds = h->cfg.maxDepth + 1;
     uint32_t* words = (uint32_t*)(base + L.words);
     const size_t nMetas = (size_t)L.rounds * (2 + PT_MAX_KINDS);
     for (size_t m = 0; m < nMetas; m++) {
@@ -981,10 +976,7 @@ int ptgpu_render_noalloc(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount,
     if (ordered) HIPCHECK(hipStreamWaitEvent(h->stream, g_scratchDone[h->cfg.device], 0));
     // the array keeps the last call's contents (of this or any other handle on the device): counters start at zero
     HIPCHECK(hipMemsetAsync(words, 0, nMetas * PT_QMETA_WORDS * 4 + (PT_TASK_WORDS + PT_POOL_WORDS) * 4, h->stream));
-    // ... and so do the chain lanes' radiance records: whatever another call's layout left there must not be taken
-    // for a record of this batch
-    if (L.lanes > 1)
-      HIPCHECK(hipMemsetAsync(base + L.Lacc + (size_t)L.capSlots * 16, 0, (size_t)(L.lanes - 1) * L.capSlots * 16, h->stream));
+    // (every radiance record a batch reads was written by that batch: nothing of them needs clearing)
     LaunchCfg lc = makeLaunchCfg(h);
     launchInitMetas(lc, (QMeta*)(base + L.desc), words, (uint32_t)nMetas);
     HIPCHECK(hipGetLastError());

@@ -134,9 +134,11 @@ struct Wavefront {
   float4* rayD;               //                     (dir.xyz, 0)
   float4* hitA;               // hit queue (filled by extend, hits only): (hit position.xyz, triangle id)
   float4* hitB;               //                                          (u, v, lane slot, t)
-  float4* Lacc;               // per lane slot: radiance gathered by this lane (xyz); w of a view-ray slot: bits of
-                              // (material index + 1) when the view ray hit, 0 when it missed
-  float4* thr;                // per lane slot: throughput of the chain (xyz), depth (w)
+  float4* Lacc;               // radiance records.  [0, capSlots): per path slot, the sample's computeLdirect sum or sampleSky
+                              // (xyz); w: bits of (material index + 1) when the view ray hit (above bit 24: which
+                              // chains' first rays hit, see chainMask), 0 when it missed.  Then, per vertex of a chain,
+                              // record lane slot + round * chainStride: computeLdirect at that vertex (xyz), w: bits of
+                              // (material index + 1) | (the chain goes on) << 31, or 0 where the chain has no vertex
   uint2* rng;                 // per lane slot: generator state
   float4* shO;                // shadow queues, kind-major: (origin.xyz, lane slot)
   float4* shD;                //                            (dir.xyz, light distance)
@@ -155,10 +157,8 @@ struct Wavefront {
   uint32_t capQueue;          // entries per ray / shadow queue (capSlots * max(1, numIndirect) in mode 1)
   uint32_t capHit;            // entries of the hit queue: capQueue + PT_SEGS * PT_HIT_SLACK
   uint32_t lanes;             // 1 + numIndirect in mode 1, else 1
-  uint32_t tag;               // non-zero, different for every batch ever rendered by this process: the w of a chain
-                              // lane's radiance record (lane slots from capSlots up) holds the tag of the batch that
-                              // last wrote it, and a record with another tag reads as zero -- so nobody has to clear
-                              // the five chain records of every shaded view-ray hit (most are never added to)
+  uint32_t chainStride;       // numIndirect * capSlots: from a chain vertex's record to that of the next bounce round
+  uint32_t recRounds;         // bounce rounds that have records: maxDepth + 1
   FastDiv divCap;             // division by capSlots
   uint32_t round;             // bounce round of the stage being launched (0 = hits of the rays the view-ray hits spawned)
   // Shading that traces the rays it spawns (k_shade<.., FUSE>, fuse != 0).  The hits of a stage's continuation rays go
@@ -167,7 +167,8 @@ struct Wavefront {
   float4* hitOutA; float4* hitOutB;
   uint32_t rayCap;            // entries of rayO / rayD
   uint32_t fuse;
-  uint32_t chainMask;         // 1: the tag word of a view-ray record is (chains whose first ray hit) << 24 | tag
+  uint32_t chainMask;         // 1 (fuse in mode 1): the tag word of a view-ray record is (chains whose first ray hit)
+                              // << 24 | tag, and a chain vertex's record says whether the chain goes on
 };
 
 // Scene and tables of the fused shading variant share a shade workgroup's LDS; above this the general path runs.
@@ -216,12 +217,6 @@ void launchExtend(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, co
 void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
                  const Wavefront& wf, bool primary);
 void launchConnect(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, float area);
-// Radiance record of lane slot `slot` as the adding kernels read it: a chain lane written by an earlier batch is zero.
-__device__ __forceinline__ float4 loadLacc(const float4* Lacc, uint32_t slot, uint32_t capSlots, uint32_t tag) {
-  float4 L = Lacc[slot];
-  if (slot >= capSlots && __float_as_uint(L.w) != tag) L = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(tag));
-  return L;
-}
 // primary: the queue was filled by the shading of view-ray hits
 void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, bool primary);
 // raygen + extend of the view rays in one traversal launch: fills wf.hitQ (counts) and the radiance records of the

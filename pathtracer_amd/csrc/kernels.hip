@@ -1026,13 +1026,14 @@ template <bool LDST> struct ShadeTables {
 
 // ------------------------------------------------------------------------------------------------ connect
 // Light-sample rays: Scene.trace + the body of `if(distanceY > lightDistance - FloatEpsilon)`, rendering.d:414-425.
-// At most one entry per lane slot and launch, so the read-modify-write of Lacc needs no atomics and the
-// per-lane order of additions (light 0, light 1, ..., sun, sky) is the launch order.
+// At most one entry per radiance record and launch, so the read-modify-write of Lacc needs no atomics and the
+// per-record order of additions (light 0, light 1, ..., sun, sky) is the launch order.  The record was set to
+// (0, 0, 0, tag) by the shading of the vertex (`vec3 L;`, rendering.d:399).
 template <bool LDSS, bool COUNT>
 __global__ void PT_TRAVERSAL_BOUNDS k_connect(DevScene sc, float eps, QMeta q, uint32_t segCap, const float4* __restrict__ shO,
                                                   const float4* __restrict__ shD, const float4* __restrict__ shW,
                                                   uint32_t* taskCounter, float area, float4* __restrict__ Lacc,
-                                                  uint32_t capSlots, uint32_t tag, unsigned long long* stats) {
+                                                  unsigned long long* stats) {
   __shared__ __align__(16) WorkPool pool;
   initPool(&pool);
   stageScene<LDSS>(sc);
@@ -1061,7 +1062,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_connect(DevScene sc, float eps, QMeta q, u
           if (!(G > 0.0f)) G = 0.0f;
           V3 c = xyz(w) * Le * G * area;
           uint32_t slot = f2u(ro.w);
-          float4 L = loadLacc(Lacc, slot, capSlots, tag);
+          float4 L = Lacc[slot];
           L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z;
           Lacc[slot] = L;
         }
@@ -1074,14 +1075,13 @@ __global__ void PT_TRAVERSAL_BOUNDS k_connect(DevScene sc, float eps, QMeta q, u
 // Sun and sky rays of one vertex: Scene.hitsNothing + `L += ...`, rendering.d:440-443 and 455-457.  An entry is
 // (origin, lane slot), (sun direction, n.sunDir), (sky direction, n.dir) and X; a zero direction is not traced.
 // direct: the vertex is a view-ray hit whose L nothing else adds to before this kernel; X = (color, material tag) and
-// the kernel stores L = 0 + ... with the tag (see k_accumulate) without reading it.  Otherwise X = (BRDF * color
-// scaled by the chain's throughput, -) and L is read, added to and written back when a ray got through.
+// the kernel stores L = 0 + ... with the tag (see k_accumulate) without reading it.  Otherwise X = (BRDF * color, -)
+// and L is read, added to and written back when a ray got through.
 template <bool LDSS, bool COUNT>
 __global__ void PT_TRAVERSAL_BOUNDS k_occluded(DevScene sc, float eps, V3 sunRadiance, V3 skyRadiance, int direct, QMeta q,
                                                    uint32_t segCap, const float4* __restrict__ shO, const float4* __restrict__ shD,
                                                    const float4* __restrict__ shW, const float4* __restrict__ shX,
-                                                   uint32_t* taskCounter, float4* __restrict__ Lacc, uint32_t capSlots, uint32_t tag,
-                                                   unsigned long long* stats) {
+                                                   uint32_t* taskCounter, float4* __restrict__ Lacc, unsigned long long* stats) {
   __shared__ __align__(16) WorkPool pool;
   initPool(&pool);
   stageScene<LDSS>(sc);
@@ -1114,7 +1114,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_occluded(DevScene sc, float eps, V3 sunRad
         uint32_t slot = f2u(ro.w);
         V3 Tw; float4 L;
         if (direct) { V3 color = xyz(x); Tw = v3(1, 1, 1) * (PT_BRDF * color); L = make_float4(0.0f, 0.0f, 0.0f, x.w); }
-        else { Tw = xyz(x); L = loadLacc(Lacc, slot, capSlots, tag); }
+        else { Tw = xyz(x); L = Lacc[slot]; }
         if (vSun) { V3 c = Tw * sunRadiance * a.w; L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; }
         if (vSky) { V3 c = Tw * skyRadiance * b.w; L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; }
         Lacc[slot] = L;
@@ -1137,13 +1137,13 @@ struct ShadeCtx {
 };
 
 // One computeLindirect head (rendering.d:378-385): Russian roulette, direction, ray; appended to ray queue qOut.
-// FIRST: the chain starts here, at a view-ray hit whose material is firstMat.  Its throughput (the material's colour),
-// depth (1) and generator state (the chain's stream after these three draws) follow from the lane slot and that
-// material, so they are not stored: the ray carries firstMat in the free word of its direction record and the shading
-// of its hit works them out again (most such rays hit nothing and nobody would read what was stored).
+// FIRST: the chain starts here, at a view-ray hit.  Its depth (1) and generator state (the chain's stream after these
+// three draws) follow from the lane slot, so they are not stored: the shading of the ray's hit works them out again
+// (most such rays hit nothing and nobody would read what was stored).  Otherwise the generator goes to the lane slot's
+// state; the depth of a vertex is its bounce round + 1.  No throughput is carried along a chain: every vertex keeps
+// its own computeLdirect sum and k_accumulate folds the chain from its end, as the recursion does (rendering.d:391).
 template <bool FIRST, bool FUSE>
-__device__ __forceinline__ bool bounce(ShadeCtx& cx, bool active, Rng& g, uint32_t depth, V3 T, V3 color, V3 pos, V3 normal,
-                                       uint32_t laneSlot, uint32_t firstMat) {
+__device__ __forceinline__ bool bounce(ShadeCtx& cx, bool active, Rng& g, uint32_t depth, V3 pos, V3 normal, uint32_t laneSlot) {
   bool alive = false; V3 dir = v3(0, 0, 0);
   if (active) {
     float a = g.uniform(0.0f, 1.0f);
@@ -1169,11 +1169,8 @@ __device__ __forceinline__ bool bounce(ShadeCtx& cx, bool active, Rng& g, uint32
     if (isHit) {
       uint32_t e = (cx.T + (idx & ((1u << cx.segBits) - 1u))) * cx.segCapHit + (idx >> cx.segBits);
       cx.outA[e] = f4(o + dir * h.t, u2f(h.tri));
-      cx.outB[e] = make_float4(h.u, h.v, u2f(laneSlot), FIRST ? u2f(firstMat) : 0.0f);
-      if (!FIRST) {
-        cx.wf.thr[laneSlot] = f4(T * color, u2f(depth + 1));
-        cx.wf.rng[laneSlot] = make_uint2(g.s0, g.s1);
-      }
+      cx.outB[e] = make_float4(h.u, h.v, u2f(laneSlot), 0.0f);
+      if (!FIRST) cx.wf.rng[laneSlot] = make_uint2(g.s0, g.s1);
     }
     return isHit;
   } else {
@@ -1181,12 +1178,8 @@ __device__ __forceinline__ bool bounce(ShadeCtx& cx, bool active, Rng& g, uint32
     if (alive) {
       uint32_t e = cx.T * cx.segCapRay + idx;
       cx.wf.rayO[e] = f4(pos + normal * 0.1f, u2f(laneSlot));
-      cx.wf.rayD[e] = f4(dir, FIRST ? u2f(firstMat) : 0.0f);
-      if (!FIRST) {
-        // BRDF * PI * color == color: the factor the caller multiplies computeLrefl with (rendering.d:391)
-        cx.wf.thr[laneSlot] = f4(T * color, u2f(depth + 1));
-        cx.wf.rng[laneSlot] = make_uint2(g.s0, g.s1);
-      }
+      cx.wf.rayD[e] = f4(dir, 0.0f);
+      if (!FIRST) cx.wf.rng[laneSlot] = make_uint2(g.s0, g.s1);
     }
     return alive;
   }
@@ -1283,20 +1276,14 @@ __device__ __forceinline__ bool directLight(ShadeCtx& cx, const ShadeTables<LDST
 
 // computeLdirect whole (rendering.d:396-462) for the shading variant that traces its own rays: every light group's
 // sample ray (the body of k_connect), then the sun and the sky ray (the body of k_occluded), each contribution added
-// to L in that order -- the order in which the queued kernels are launched.  fromZero: L is the `vec3 L` of a
-// view-ray hit, gathered from 0 and stored with the record's tag word in any case; otherwise L is the chain's record,
-// read when the first contribution arrives and written back if there was one.
+// to L in that order -- the order in which the queued kernels are launched.  Returns the `vec3 L` of the vertex,
+// gathered from 0; the caller stores it with the record's tag word.
 template <bool LDST>
-__device__ __forceinline__ void directLightTraced(ShadeCtx& cx, const ShadeTables<LDST>& tb, bool active, Rng& g, V3 x, V3 normalX, V3 Tw,
-                                                  uint32_t tagWord, bool fromZero, uint32_t laneSlot) {
+__device__ __forceinline__ V3 directLightTraced(ShadeCtx& cx, const ShadeTables<LDST>& tb, bool active, Rng& g, V3 x, V3 normalX, V3 Tw) {
   const DevScene& sc = cx.sc; const DevCfg& cfg = cx.cfg;
   const float eps = cfg.eps;
-  float4 L = make_float4(0.0f, 0.0f, 0.0f, u2f(tagWord));
-  bool have = fromZero, dirty = false;
-  auto add = [&](V3 c) {
-    if (!have) { L = loadLacc(cx.wf.Lacc, laneSlot, cx.wf.capSlots, cx.wf.tag); have = true; }
-    L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; dirty = true;
-  };
+  V3 L = v3(0.0f, 0.0f, 0.0f);
+  auto add = [&](V3 c) { L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; };
   if (active) {
     Hit h; uint32_t cN = 0, cT = 0;
     if (cfg.hasLights) {
@@ -1332,8 +1319,8 @@ __device__ __forceinline__ void directLightTraced(ShadeCtx& cx, const ShadeTable
         if (vSky) add(Tw * cfg.skyRadiance * s.sSky);
       }
     }
-    if (fromZero || dirty) cx.wf.Lacc[laneSlot] = L;
   }
+  return L;
 }
 
 // PRIMARY: the part of computeL after the view-ray trace has hit (rendering.d:472-477); the generator of
@@ -1365,10 +1352,16 @@ __device__ __forceinline__ void vertexTables(const ShadeTables<LDST>& tb, uint32
 // continuation (rendering.d:376-394).  Called from converged code (the appends rank lanes with a wave ballot);
 // `active` says whether the lane has a vertex.  g: the vertex's generator (view-ray hit: stream 0 of its sample past
 // the two jitter draws; chain hit: the chain's stream).
+// recSlot: the vertex's radiance record.  A view-ray hit: its path slot, (L, tag word).  A chain vertex of bounce round
+// r: lane slot + r * chainStride, (L, (material index + 1) | continues << 31) -- computeLdirect at that vertex alone,
+// and whether the chain has a vertex in round r + 1.  Where the rays are traced in place the record is written once,
+// complete; where they are queued, shading writes (0, 0, 0, material index + 1), the kernels that trace the shadow
+// rays add to it, and the record of round r + 1 is marked absent (w = 0) until the shading of that round finds the
+// continuation ray's hit in its queue -- every record is written in the batch that reads it.
 template <bool PRIMARY, bool LDST, bool FUSE>
 __device__ __forceinline__ void shadeVertex(ShadeCtx& cx, const ShadeTables<LDST>& tb, bool active, V3 hitPos, V3 normal, V3 color,
-                                            uint32_t matTag, V3 Tp, uint32_t depth, Rng& g, uint32_t gp, uint32_t sampleIdx,
-                                            uint32_t laneSlot) {
+                                            uint32_t matTag, uint32_t depth, Rng& g, uint32_t gp, uint32_t sampleIdx,
+                                            uint32_t laneSlot, uint32_t recSlot) {
   const DevCfg& cfg = cx.cfg; const Wavefront& wf = cx.wf;
   uint32_t tagWord = matTag;
   // every chain has a generator stream of its own, so the place of the loop in this kernel is free: the traced
@@ -1384,23 +1377,31 @@ __device__ __forceinline__ void shadeVertex(ShadeCtx& cx, const ShadeTables<LDST
       uint32_t lane = (c + 1) * wf.capSlots + laneSlot;
       Rng gc; gc.s0 = 1; gc.s1 = 0;
       if (active) gc.seed(cfg.seed, gp, sampleIdx, c + 1);
-      if (bounce<true, FUSE>(cx, active, gc, 0, v3(1, 1, 1), color, hitPos, normal, lane, matTag - 1u)) hitMask |= 1u << c;
+      if (bounce<true, FUSE>(cx, active, gc, 0, hitPos, normal, lane)) hitMask |= 1u << c;
+      // queued: whether the ray hits is not known yet -- the chain's first record is absent until round 0 shades the hit
+      if (!FUSE && active) ((float*)&wf.Lacc[lane])[3] = 0.0f;
     }
     return hitMask;
   };
-  V3 Tw = Tp * (PT_BRDF * color);
+  const V3 Tw = v3(1, 1, 1) * (PT_BRDF * color);
   if constexpr (FUSE) {
-    if (PRIMARY && cfg.mode == 1) { uint32_t hitMask = chainHeads(); if (wf.chainMask) tagWord |= hitMask << 24; }
-    directLightTraced(cx, tb, active, g, hitPos, normal, Tw, tagWord, PRIMARY, laneSlot);
+    if (PRIMARY && cfg.mode == 1) { uint32_t hitMask = chainHeads(); tagWord |= hitMask << 24; }
+    const V3 L = directLightTraced(cx, tb, active, g, hitPos, normal, Tw);
+    bool more = false;
+    if (!PRIMARY && cfg.mode == 1) more = bounce<false, FUSE>(cx, active, g, depth, hitPos, normal, laneSlot);
+    if (active) wf.Lacc[recSlot] = f4(L, u2f(PRIMARY ? tagWord : (matTag | (more ? 0x80000000u : 0u))));
   } else {
     const bool direct = envDirect(cfg, cx.sc, PRIMARY);
-    bool env = directLight(cx, tb, active, g, hitPos, normal, Tw, direct ? f4(color, u2f(tagWord)) : f4(Tw, 0.0f), laneSlot);
+    bool env = directLight(cx, tb, active, g, hitPos, normal, Tw, direct ? f4(color, u2f(tagWord)) : f4(Tw, 0.0f), recSlot);
     // `vec3 L;` of computeLdirect (rendering.d:399) + the tag; when the sun / sky entry carries it, the kernel that
     // traces them stores L
-    if (PRIMARY && active && !(direct && env)) wf.Lacc[laneSlot] = make_float4(0.0f, 0.0f, 0.0f, u2f(tagWord));
+    if (active && !(direct && env)) wf.Lacc[recSlot] = make_float4(0.0f, 0.0f, 0.0f, u2f(tagWord));
     if (PRIMARY && cfg.mode == 1) chainHeads();
+    if (!PRIMARY && cfg.mode == 1) {
+      if (active && depth <= cfg.maxDepth) ((float*)&wf.Lacc[recSlot + wf.chainStride])[3] = 0.0f;     // the next round's, until it is shaded
+      bounce<false, FUSE>(cx, active, g, depth, hitPos, normal, laneSlot);
+    }
   }
-  if (!PRIMARY && cfg.mode == 1) bounce<false, FUSE>(cx, active, g, depth, Tp, color, hitPos, normal, laneSlot, 0u);
 }
 
 // Ray counts of the traced variants: wave sums, one atomic per wave and counter.
@@ -1462,8 +1463,9 @@ __device__ __forceinline__ void shadeBody(const DevScene& sc, const DevCfg& cfg,
   for (uint32_t base = tk.begin; base < tk.end; base += blockDim.x) {
     uint32_t j = base + threadIdx.x;
     bool active = j < tk.end;
-    V3 Tp = v3(1, 1, 1), hitPos = v3(0, 0, 0), normal = v3(0, 0, 1), color = v3(0, 0, 0);
-    uint32_t laneSlot = 0, depth = 0, gp = 0, sampleIdx = 0;
+    V3 hitPos = v3(0, 0, 0), normal = v3(0, 0, 1), color = v3(0, 0, 0);
+    uint32_t laneSlot = 0, gp = 0, sampleIdx = 0;
+    const uint32_t depth = PRIMARY ? 0u : round + 1u;
     uint32_t matTag = 0;                     // material index + 1: marks the slot as a view-ray hit (k_accumulate)
     Rng g; g.s0 = 1; g.s1 = 0;
     if (active) {
@@ -1485,15 +1487,13 @@ __device__ __forceinline__ void shadeBody(const DevScene& sc, const DevCfg& cfg,
         sampleIdx = cfg.sampleBase + ((uint32_t)acc[gp].w + s) * cfg.sampleStride;
         g.seed(cfg.seed, gp, sampleIdx, chain);
         g.next(); g.next(); g.next();                                  // Russian roulette, psi, phi of the chain's head
-        float4 m0 = tb.mat(f2u(hb.w));
-        Tp = v3(1, 1, 1) * v3(m0.y, m0.z, m0.w); depth = 1;
       } else {
-        float4 t4 = wf.thr[laneSlot]; Tp = xyz(t4); depth = f2u(t4.w);
         uint2 r = wf.rng[laneSlot]; g.s0 = r.x; g.s1 = r.y;
       }
       vertexTables(tb, tri, hb.x, hb.y, normal, color, matTag);
     }
-    shadeVertex<PRIMARY, LDST, FUSE>(cx, tb, active, hitPos, normal, color, matTag, Tp, depth, g, gp, sampleIdx, laneSlot);
+    shadeVertex<PRIMARY, LDST, FUSE>(cx, tb, active, hitPos, normal, color, matTag, depth, g, gp, sampleIdx, laneSlot,
+                                     PRIMARY ? laneSlot : laneSlot + round * wf.chainStride);
   }
   if constexpr (!OWN_SEGMENT) break;
   else {
@@ -1646,7 +1646,7 @@ __global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_SAMPLE_WAVES) k_sample_t
         wf.Lacc[i] = f4(sampleSky(pr.d), 0.0f);                                     // rendering.d:480
       }
     }
-    shadeVertex<true, true, true>(cx, tb, active, hitPos, normal, color, matTag, v3(1, 1, 1), 0u, g, gp, sampleIdx, i);
+    shadeVertex<true, true, true>(cx, tb, active, hitPos, normal, color, matTag, 0u, g, gp, sampleIdx, i, i);
     if ((threadIdx.x & 63u) == 0) atomicSub(&sBusy, 1u);              // after the run's appends
   }
   flushTraced(cx, true);
@@ -1758,11 +1758,31 @@ __global__ void __launch_bounds__(256) k_accumulate(ViewMasks masks, DevCfg cfg,
       float4 m = mats[tag - 1u];
       add = m.x * v3(m.y, m.z, m.w) + add;
       if (cfg.mode == 1) {
+        // computeLindirect of every chain, folded from the chain's end as the recursion returns (rendering.d:391, 372):
+        // Lrefl(v) = Ldirect(v) + color(v) * Lrefl(next vertex), or + 0 where the chain ends; the chain is worth
+        // color(view-ray hit) * Lrefl(its first vertex).  Vertex r of chain c keeps (Ldirect, material + 1 | continues << 31)
+        // in record slot + (c + 1) * capSlots + r * chainStride.
+        const V3 color0 = v3(m.y, m.z, m.w);
         V3 sum = v3(0, 0, 0);
         for (uint32_t c = 0; c < cfg.numIndirect; c++) {
-          if (!((chains >> (c & 31u)) & 1u)) continue;
-          float4 Lc = wf.Lacc[(size_t)(c + 1) * wf.capSlots + slot];
-          sum = sum + (f2u(Lc.w) == wf.tag ? xyz(Lc) : v3(0, 0, 0));          // nothing was added to a record of another batch
+          const uint32_t rec0 = (c + 1u) * wf.capSlots + slot;
+          // how many vertices the chain has: told by the chain mask and the `continues` bits where shading traced its own
+          // rays, else by the records' tag words (shading marked the record after the last vertex absent)
+          uint32_t n = 0;
+          if (wf.chainMask) {
+            bool more = (chains >> (c & 31u)) & 1u;
+            while (more && n < wf.recRounds) { more = f2u(wf.Lacc[rec0 + n * wf.chainStride].w) >> 31; n++; }
+          } else {
+            while (n < wf.recRounds && (f2u(wf.Lacc[rec0 + n * wf.chainStride].w) & 0x7FFFFFFFu) != 0u) n++;
+          }
+          if (n == 0) continue;                                              // `sum += 0`
+          V3 R = v3(0, 0, 0);
+          for (uint32_t r = n; r-- > 0;) {
+            const float4 Lr = wf.Lacc[rec0 + r * wf.chainStride];
+            const float4 mr = mats[(f2u(Lr.w) & 0x7FFFFFFFu) - 1u];
+            R = xyz(Lr) + (r + 1 == n ? v3(0, 0, 0) : v3(mr.y, mr.z, mr.w) * R);
+          }
+          sum = sum + color0 * R;
         }
         add = add + sum / (float)cfg.numIndirect;
       }
@@ -1985,7 +2005,7 @@ void launchConnect(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, c
   Geo g = traversalGeo(lc, sc, wf.capQueue);
   size_t e = (size_t)kind * wf.capQueue;
   PT_DISPATCH_LC(k_connect, sc, cfg.eps, wf.sh[kind], wf.capQueue / PT_SEGS, (const float4*)(wf.shO + e), (const float4*)(wf.shD + e),
-                 (const float4*)(wf.shW + e), wf.taskCounters + (1 + kind) * PT_TASK_PARTS, area, wf.Lacc, wf.capSlots, wf.tag, wf.stats);
+                 (const float4*)(wf.shW + e), wf.taskCounters + (1 + kind) * PT_TASK_PARTS, area, wf.Lacc, wf.stats);
 }
 
 void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, bool primary) {
@@ -1993,7 +2013,7 @@ void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, 
   size_t e = (size_t)kind * wf.capQueue;
   PT_DISPATCH_LC(k_occluded, sc, cfg.eps, cfg.sunRadiance, cfg.skyRadiance, envDirect(cfg, sc, primary) ? 1 : 0, wf.sh[kind],
                  wf.capQueue / PT_SEGS, (const float4*)(wf.shO + e), (const float4*)(wf.shD + e), (const float4*)(wf.shW + e),
-                 (const float4*)wf.shX, wf.taskCounters + (1 + kind) * PT_TASK_PARTS, wf.Lacc, wf.capSlots, wf.tag, wf.stats);
+                 (const float4*)wf.shX, wf.taskCounters + (1 + kind) * PT_TASK_PARTS, wf.Lacc, wf.stats);
 }
 
 void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,

@@ -58,10 +58,12 @@ def test_image_equals_golden_mode0(require_gpu, name):
     assert np.array_equal(got.view(np.uint32), g['radiance_mode0_64spp'].view(np.uint32))
 
 
-@pytest.mark.parametrize('name', ['cornell-box', 'chest1'])
-def test_image_close_to_oracle_with_same_streams_mode1(require_gpu, name, flats):
+@pytest.mark.parametrize('name', NAMES)
+def test_image_equals_oracle_with_same_streams_mode1(require_gpu, name, flats):
     """Indirect chains (rendering.d:376-394, 474-477): the same rays are traced and the same decisions taken as in the
-    oracle (counts equal exactly); radiance agrees to rounding (see the module docstring)."""
+    oracle (counts equal exactly), and the radiance is the same bits: every chain vertex keeps its own computeLdirect
+    sum and the chain is folded from its end, in the order the recursion returns.  cornell-box and chest1 take the
+    kernels that trace the rays they spawn, the teapot the queued ones."""
     W = H = 64
     sky = name != 'cornell-box'
     pt = make_tracer(name, W, H, has_sky=int(sky), mode=1, seed=2024)
@@ -75,8 +77,8 @@ def test_image_close_to_oracle_with_same_streams_mode1(require_gpu, name, flats)
     rays = st.raysPrimary + st.raysLight + st.raysIndirect
     assert int(rays) == int(cn[0]) and int(st.raysOcclusion) == int(cn[1])
     assert np.array_equal(got['n'], ref['n'])
-    assert np.allclose(got['sum'], ref['sum'], rtol=2e-5, atol=1e-7)
-    assert rel_rmse(got['color'], ref['color']) < 1e-6
+    assert np.array_equal(got['sum'].view(np.uint32), ref['sum'].view(np.uint32))
+    assert np.array_equal(got['color'].view(np.uint32), g['radiance_mode1_16spp'].view(np.uint32))
     assert np.isfinite(got['sum']).all() and (got['sum'] >= (-0.0036 * 16 * 6 if sky else 0)).all()
 
 
@@ -279,7 +281,7 @@ def test_full_size_properties(require_gpu):
 def test_lights_and_sky_together_equal_oracle_with_same_streams(require_gpu, flags, mode):
     """A scene with a light group AND the sky: the light-sample kernel adds to a vertex's radiance first, the sun/sky
     kernel then reads, adds and writes it back (it may store it outright only when nothing precedes it).  Same streams
-    as the oracle: mode 0 bit-identical, mode 1 identical rays and radiance to rounding."""
+    as the oracle: bit-identical in both modes (mode 1 through the queued kernels, scene in LDS and in global memory)."""
     fl = soup(1500, seed=21, size=12.0)                   # big triangles: most view rays hit, many shadow rays are blocked
     W, H = 96, 64
     cam = P.Camera(30.0, H / W).setTransform((250, 180, 160), (0, 0, 0), (0, 0, 1))
@@ -294,10 +296,7 @@ def test_lights_and_sky_together_equal_oracle_with_same_streams(require_gpu, fla
     st = pt.stats()
     assert st.raysLight > 0 and st.raysOcclusion > 0
     assert int(st.raysPrimary + st.raysLight + st.raysIndirect) == int(cn[0]) and int(st.raysOcclusion) == int(cn[1])
-    if mode == 0:
-        assert np.array_equal(got['sum'].view(np.uint32), ref['sum'].view(np.uint32))
-    else:
-        assert np.allclose(got['sum'], ref['sum'], rtol=2e-5, atol=1e-7)
+    assert np.array_equal(got['sum'].view(np.uint32), ref['sum'].view(np.uint32))
 
 
 def test_frame_transfers_pinned_staged_and_overlapped(require_gpu):

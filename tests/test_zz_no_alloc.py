@@ -63,10 +63,10 @@ def test_noalloc_limits_and_errors(require_gpu):
     m1 = make_tracer('chest1', 512, 512, has_sky=1, mode=1, seed=1)
     with pytest.raises(P.PtError) as e:
         m1.render_noalloc(0, 512 * 512, 1)
-    assert 'exceeds the 131072 samples' in str(e.value)
-    m1.render_noalloc(0, 131072, 1)
+    assert 'exceeds the 65536 samples' in str(e.value)
+    m1.render_noalloc(0, 65536, 1)
     r1 = make_tracer('chest1', 512, 512, has_sky=1, mode=1, seed=1)
-    r1.render(0, 131072, 1)
+    r1.render(0, 65536, 1)
     a, b = r1.read_pixels(), m1.read_pixels()
     assert np.array_equal(a['sum'].view(np.uint32), b['sum'].view(np.uint32)) and np.array_equal(a['n'], b['n'])
     t1 = make_tracer('teapot', 512, 512, has_sky=1, mode=1, seed=1)
