@@ -168,6 +168,7 @@ struct Hit { float t, u, v; uint32_t tri; bool front; };
 //   PT_PROBE_TRI2         every triangle test of a scene in global memory fetches a second, random triangle as well
 //                         (what triangle traffic costs: +18-20 % on the 10 M-triangle soup's traversal kernels)
 //   PT_PROBE_A / _B / _C  the traced shading without its chain traversals / its chain loop / its sun and sky traversals
+//   PT_PROBE_D            the chains' directions without angleToDirection
 //                         (wrong images: timing only)
 #if defined(PT_STAMP) || defined(PT_SLOTS)
 #define PT_STAMP_ON 1
@@ -1150,7 +1151,11 @@ __device__ __forceinline__ bool bounce(ShadeCtx& cx, bool active, Rng& g, uint32
     if (!(a > cx.cfg.rrProb || depth > cx.cfg.maxDepth)) {
       float psi = g.uniform(0.0f, 2.0f * PT_PI_F);
       float phi = g.uniform(0.0f, PT_PI_2_F);
+#ifdef PT_PROBE_D
+      dir = normal + v3(phi, psi, 0.0f) * 1e-3f;
+#else
       dir = angleToDirection(phi, psi, normal);
+#endif
       alive = true;
     }
   }
@@ -1619,7 +1624,12 @@ __global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_SAMPLE_WAVES) k_sample_t
     const bool valid = i < nslots;
     if (valid) mine++;
     uint32_t s, gp = slotPixel(cfg, pm, valid ? i : 0u, s);
-    const bool constant = valid && masks.constantSky && maskBit(masks.constantSky, gp);
+    // the pixel's mask words and its sample count are asked for together: one memory round trip in front of a run, not
+    // one for the constant-sky bit and a second for the rest
+    const uint32_t skyWord = masks.constantSky ? masks.constantSky[gp >> 5] : 0u;
+    const uint32_t coveredWord = masks.covered ? masks.covered[gp >> 5] : 0u;
+    const float accW = acc[gp].w;
+    const bool constant = valid && ((skyWord >> (gp & 31u)) & 1u);
     const bool live = valid && !constant;
     bool active = false;
     V3 hitPos = v3(0, 0, 0), normal = v3(0, 0, 1), color = v3(0, 0, 0);
@@ -1627,9 +1637,9 @@ __global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_SAMPLE_WAVES) k_sample_t
     Rng g; g.s0 = 1; g.s1 = 0;
     if (constant) { culled++; nConst++; }
     if (live) {
-      PrimaryRay pr = primaryRayFrom(cfg, gp, s, acc[gp].w, true);
+      PrimaryRay pr = primaryRayFrom(cfg, gp, s, accW, true);
       bool enter;
-      if (masks.covered) enter = maskBit(masks.covered, gp);
+      if (masks.covered) enter = (coveredWord >> (gp & 31u)) & 1u;
       else {
         RayInv ri = makeRayInv(cfg.cam.pos, pr.d);
         float tn;
@@ -1646,7 +1656,8 @@ __global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_SAMPLE_WAVES) k_sample_t
         wf.Lacc[i] = f4(sampleSky(pr.d), 0.0f);                                     // rendering.d:480
       }
     }
-    shadeVertex<true, true, true>(cx, tb, active, hitPos, normal, color, matTag, 0u, g, gp, sampleIdx, i, i);
+    // (a run none of whose view rays hit -- a tile of sky -- has nothing to shade: two runs in three of the chest frame)
+    if (__any(active)) shadeVertex<true, true, true>(cx, tb, active, hitPos, normal, color, matTag, 0u, g, gp, sampleIdx, i, i);
     if ((threadIdx.x & 63u) == 0) atomicSub(&sBusy, 1u);              // after the run's appends
   }
   flushTraced(cx, true);
