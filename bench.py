@@ -102,7 +102,7 @@ def profile_json(workload):
 # kernel kind (PtStats.kernelMs index, pathtracer_amd.PT_K_NAMES) -> the kernel it times
 KERNEL_OF = {'extend': 'k_extend / k_extend_refill', 'connect': 'k_connect', 'occluded': 'k_occluded', 'shade': 'k_shade',
              'accumulate': 'k_accumulate', 'other': 'k_scan', 'raygen': 'k_raygen', 'raygen_extend': 'k_raygen_extend',
-             'shade_occluded': 'k_shade_occluded', 'shade_traced': 'k_shade_traced<false>', 'sample_traced': 'k_sample_traced'}
+             'shade_occluded': 'k_shade_occluded', 'shade_traced': 'k_shade_traced<false>', 'sample_traced': 'k_sample_traced', 'pixel_traced': 'k_pixel_traced'}
 
 
 def kernel_work(kind, st, visits, npix_launches):
@@ -120,6 +120,10 @@ def kernel_work(kind, st, visits, npix_launches):
         rec = (S - const) * (4.0 + 16.0) + st.chainHitsFromSample * 32.0
         return S, rec, closest * nc + anyh * na, closest * tc + anyh * ta, \
             'per sample outside constant sky: 4 B sample count read + 16 B radiance record written; 32 B per hit of a chain\'s first ray'
+    if kind == 'pixel_traced':
+        closest, anyh = fp + wl + wi, wo
+        return S, npix_launches * 32.0, closest * nc + anyh * na, closest * tc + anyh * ta, \
+            '32 B of accumulator per pixel and launch (read, written back); a sample leaves no record'
     if kind == 'shade_traced':
         units = H - Hp
         closest, anyh = (fl - wl) + (fi - wi), fo - wo

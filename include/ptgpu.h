@@ -90,6 +90,10 @@ typedef struct PtConfig {
 #define PT_FLAG_NO_TREELETS 1024u   /* scenes traversed from global memory: keep the builder's order of the node pairs
                                      (default: pairs are laid out so that a 128-byte line holds a pair with
                                      descendants of it)                                                              */
+#define PT_FLAG_NO_PIXEL_SUMS 2048u /* mode 0 on the one-kernel-per-sample path: keep a radiance record per sample and add the
+                                     records up in a second launch, as mode 1 does (default, for windows of at least
+                                     786432 pixels or one sample per pixel: a lane renders the samples of one pixel one
+                                     after the other and adds them up in registers; same sums, bit for bit)            */
 
 typedef struct PtMaterial { float emissive; float color[3]; } PtMaterial;        /* rendering.d:33-37 */
 typedef struct PtPixel { float color[3]; float n; float sum[3]; } PtPixel;        /* rendering.d:24-30 */
@@ -101,7 +105,8 @@ enum { PT_K_EXTEND = 0, PT_K_CONNECT = 1, PT_K_OCCLUDED = 2, PT_K_SHADE = 3, PT_
        PT_K_SHADE_OCCLUDED = 8,  /* the sun / sky traversal kernel that shades the view-ray hits it reads            */
        PT_K_SHADE_TRACED = 9,    /* shading of chain hits that traces the rays it spawns, all bounce rounds          */
        PT_K_SAMPLE_TRACED = 10,  /* a whole sample per lane: raygen, view ray, shading and the rays it spawns        */
-       PT_K_COUNT = 11 };
+       PT_K_PIXEL_TRACED = 11,   /* a whole pixel per lane (mode 0): its samples one after the other, summed in registers */
+       PT_K_COUNT = 12 };
 
 typedef struct PtStats {
   uint64_t raysPrimary;      /* Scene.trace calls from computeL             (rendering.d:471)            */

@@ -9,8 +9,9 @@ LIB_PATH = os.environ.get('PTGPU_LIBRARY') or os.path.join(_HERE, 'libptgpu.so')
 PT_OK, PT_E_INVALID, PT_E_STATE, PT_E_DEVICE, PT_E_IO, PT_E_NOMEM = 0, -1, -2, -3, -4, -5
 PT_FLAG_COUNT_VISITS, PT_FLAG_NO_LDS_SCENE, PT_FLAG_TIME_KERNELS, PT_FLAG_NO_COVERAGE_MASK = 1, 2, 4, 8
 PT_FLAG_GPU_BVH, PT_FLAG_HOST_BVH, PT_FLAG_NO_GRAPH, PT_FLAG_NO_FUSE, PT_FLAG_QUEUED_VIEW_RAYS, PT_FLAG_NO_TREELETS, PT_FLAG_STATIC_RUNS = 16, 32, 64, 128, 256, 1024, 512
+PT_FLAG_NO_PIXEL_SUMS = 2048
 PT_K_NAMES = ('extend', 'connect', 'occluded', 'shade', 'accumulate', 'other', 'raygen', 'raygen_extend', 'shade_occluded',
-              'shade_traced', 'sample_traced')
+              'shade_traced', 'sample_traced', 'pixel_traced')
 
 
 class PtConfig(C.Structure):
@@ -30,7 +31,7 @@ class PtStats(C.Structure):
                 ('hitsPrimary', C.c_uint64), ('raysPrimaryInShade', C.c_uint64), ('raysLightInShade', C.c_uint64), ('raysIndirectInShade', C.c_uint64), ('raysOcclusionInShade', C.c_uint64),
                 ('raysLightInSample', C.c_uint64), ('raysIndirectInSample', C.c_uint64), ('raysOcclusionInSample', C.c_uint64),
                 ('chainHitsFromSample', C.c_uint64), ('samplesConstantSky', C.c_uint64), ('sceneBytes', C.c_uint64),
-                ('kernelMs', C.c_double * 11), ('kernelLaunches', C.c_uint64 * 11), ('renderMs', C.c_double),
+                ('kernelMs', C.c_double * 12), ('kernelLaunches', C.c_uint64 * 12), ('renderMs', C.c_double),
                 ('numTriangles', C.c_uint32), ('numNodes', C.c_uint32), ('bvhDepth', C.c_uint32),
                 ('numLightGroups', C.c_uint32), ('sceneInLds', C.c_uint32), ('bvhOnGpu', C.c_uint32),
                 ('bvhBuildSeconds', C.c_double), ('maskBuildMs', C.c_double)]

@@ -230,6 +230,14 @@ void launchShadeOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& 
 // wf.rayOut = the hit queue of the chains' first rays
 void launchSampleTraced(const LaunchCfg& lc, const SceneBox& box, const ViewMasks& masks, const DevScene& sc, const DevCfg& cfg,
                         const PixMap& pm, const float4* acc, uint32_t nslots, const Wavefront& wf);
+// mode 0 with wf.fuse: the pm.k samples of every pixel of pm, one pixel per lane, added to acc in sample order -- a
+// batch's whole-sample launch and its accumulate in one, with no radiance records in between; any pm.k
+void launchPixelTraced(const LaunchCfg& lc, const SceneBox& box, const ViewMasks& masks, const DevScene& sc, const DevCfg& cfg,
+                       const PixMap& pm, float4* acc, const Wavefront& wf);
+// Whether a window of npix pixels takes that path rather than whole-sample launches + accumulate: its columns of 64
+// pixels are the units of work, and a wave walks a column's samples one after the other, so there have to be enough
+// columns for the waves of the chip -- or one sample each, where a column is no more work than a run.
+inline bool pixelSumsPay(uint64_t npix, uint32_t spp) { return spp == 1 || npix >= 64ull * 12288ull; }
 void launchAccumulate(const LaunchCfg& lc, const ViewMasks& masks, const DevCfg& cfg, const PixMap& pm, float4* acc,
                       const Wavefront& wf, const DevScene& sc);
 

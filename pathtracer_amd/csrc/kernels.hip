@@ -1366,7 +1366,7 @@ __device__ __forceinline__ void vertexTables(const ShadeTables<LDST>& tb, uint32
 template <bool PRIMARY, bool LDST, bool FUSE>
 __device__ __forceinline__ void shadeVertex(ShadeCtx& cx, const ShadeTables<LDST>& tb, bool active, V3 hitPos, V3 normal, V3 color,
                                             uint32_t matTag, uint32_t depth, Rng& g, uint32_t gp, uint32_t sampleIdx,
-                                            uint32_t laneSlot, uint32_t recSlot) {
+                                            uint32_t laneSlot, uint32_t recSlot, float4* recOut = nullptr) {
   const DevCfg& cfg = cx.cfg; const Wavefront& wf = cx.wf;
   uint32_t tagWord = matTag;
   // every chain has a generator stream of its own, so the place of the loop in this kernel is free: the traced
@@ -1394,7 +1394,10 @@ __device__ __forceinline__ void shadeVertex(ShadeCtx& cx, const ShadeTables<LDST
     const V3 L = directLightTraced(cx, tb, active, g, hitPos, normal, Tw);
     bool more = false;
     if (!PRIMARY && cfg.mode == 1) more = bounce<false, FUSE>(cx, active, g, depth, hitPos, normal, laneSlot);
-    if (active) wf.Lacc[recSlot] = f4(L, u2f(PRIMARY ? tagWord : (matTag | (more ? 0x80000000u : 0u))));
+    if (active) {
+      const float4 rec = f4(L, u2f(PRIMARY ? tagWord : (matTag | (more ? 0x80000000u : 0u))));
+      if (recOut) *recOut = rec; else wf.Lacc[recSlot] = rec;       // (recOut: the caller adds the sample up itself)
+    }
   } else {
     const bool direct = envDirect(cfg, cx.sc, PRIMARY);
     bool env = directLight(cx, tb, active, g, hitPos, normal, Tw, direct ? f4(color, u2f(tagWord)) : f4(Tw, 0.0f), recSlot);
@@ -1677,6 +1680,127 @@ __global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_SAMPLE_WAVES) k_sample_t
   if (threadIdx.x < segsPer) {
     const uint32_t n = sCnt[0];
     wf.rayOut.count[T + threadIdx.x] = (n + segsPer - 1u - threadIdx.x) >> cx.segBits;      // hit idx went to segment idx % segsPer
+  }
+}
+
+// Mode 0 on the same scenes, frames large enough to fill the chip with pixel tiles: a whole PIXEL per lane.  A wave
+// takes a column of 64 pixels (a tile) and walks their samples in order -- raygen, view ray, shading with every ray
+// traced in place, exactly the code of k_sample_traced -- adding each sample to the pixels' sums in registers as
+// k_accumulate would (emissive * color + L for a hit, sampleSky for a miss, the sky constant for a constant-sky
+// pixel; rendering.d:477-482), in sample order, so the sums are the same bits.  No radiance record is written or
+// read back (32 B of HBM traffic per sample), no accumulate launch, and no state per sample: the batch is the whole
+// window whatever its size.  Columns are dealt out one at a time through the pool counters (wf.runPool; zero at
+// launch, the host clears them behind the launch), or in turn when there is no pool -- a column with all its samples
+// is a twentieth of a wave's share of a 4K frame, and pieces of four columns cost 20 % (cornell 4K 64 spp: 32.2 ms
+// against 26.8; with the sums in LDS 26.5; the recorded path 28.7).
+#ifndef PT_PIXEL_CHUNK
+#define PT_PIXEL_CHUNK 1
+#endif
+__global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_SAMPLE_WAVES) k_pixel_traced(SceneBox box, ViewMasks masks, DevScene sc, DevCfg cfg, PixMap pm,
+                                                                  float4* __restrict__ acc, Wavefront wf) {
+  __shared__ uint32_t sCnt[1 + PT_MAX_KINDS];
+  if (threadIdx.x <= PT_MAX_KINDS) sCnt[threadIdx.x] = 0;
+  stageScene<true>(sc);
+  const ShadeTables<true> tb{sc, 2 * sc.numNodes + 3 * sc.numTris};
+  tb.stage();
+  __syncthreads();
+  ShadeCtx cx{sc, cfg, wf, sCnt, 0u, 1u, 1u};
+  // the pixels' sums wait in LDS while a sample is worked out (four registers less across the sample's code)
+  __shared__ float4 sSum[PT_SAMPLE_THREADS];
+  const uint32_t columns = (pm.npix + 63u) >> 6, lane = threadIdx.x & 63u;
+  const uint32_t wavesPerGroup = blockDim.x >> 6, waveId = blockIdx.x * wavesPerGroup + (threadIdx.x >> 6), numWaves = gridDim.x * wavesPerGroup;
+  uint32_t culled = 0, nConst = 0, hits = 0, mine = 0;
+  uint32_t pending = 0, pendingCol = 0, usedUp = 0, turn = 0;
+  for (;;) {
+    uint32_t col = PT_NONE;
+    if (!wf.runPool) { col = waveId + turn * numWaves; turn++; if (col >= columns) break; }
+    else if (pending) { col = pendingCol; pendingCol += PT_POOL_COUNTERS; pending--; }
+    else {
+      uint32_t got = 0;
+      if (lane == 0) {
+        while (usedUp < PT_POOL_COUNTERS) {
+          const uint32_t c = (blockIdx.x + usedUp) % PT_POOL_COUNTERS;
+          const uint32_t r = c + PT_POOL_COUNTERS * atomicAdd(&wf.runPool[c * PT_POOL_STRIDE], (uint32_t)PT_PIXEL_CHUNK);
+          if (r < columns) { col = r; got = min((uint32_t)PT_PIXEL_CHUNK, (columns - r + PT_POOL_COUNTERS - 1) / PT_POOL_COUNTERS); break; }
+          usedUp++;
+        }
+      }
+      got = (uint32_t)__builtin_amdgcn_readfirstlane(got);
+      usedUp = (uint32_t)__builtin_amdgcn_readfirstlane(usedUp);
+      if (!got) break;
+      col = (uint32_t)__builtin_amdgcn_readfirstlane(col);
+      pending = got - 1; pendingCol = col + PT_POOL_COUNTERS;
+    }
+    const uint32_t lp = (col << 6) + lane;
+    const bool valid = lp < pm.npix;
+    const uint32_t gp = mapPixel(pm, cfg.W, valid ? lp : 0u);
+    const bool constant = valid && masks.constantSky && maskBit(masks.constantSky, gp);
+    const bool enterMask = valid && masks.covered && maskBit(masks.covered, gp);
+    float4 a = acc[gp];
+    const float accW = a.w;                                   // Pixel.n before this call: numbers the samples
+    if (valid) mine += pm.k;
+    if (constant) { culled += pm.k; nConst += pm.k; }
+    const bool live = valid && !constant;
+    if (!__any(live)) {
+      // every sample of these pixels is the sky constant (rendering.d:338)
+      if (constant) {
+        const V3 c = v3(0.682f, 0.977f, 1.0f);
+        for (uint32_t s = 0; s < pm.k; s++) { a.x += c.x; a.y += c.y; a.z += c.z; a.w += 1.0f; }
+        acc[gp] = a;
+      }
+      continue;
+    }
+    sSum[threadIdx.x] = a;
+    for (uint32_t s = 0; s < pm.k; s++) {
+      bool active = false;
+      V3 hitPos = v3(0, 0, 0), normal = v3(0, 0, 1), color = v3(0, 0, 0);
+      uint32_t matTag = 0, sampleIdx = 0;
+      Rng g; g.s0 = 1; g.s1 = 0;
+      float4 rec = make_float4(0.682f, 0.977f, 1.0f, 0.0f);       // what accumulate adds for a constant-sky pixel
+      if (live) {
+        PrimaryRay pr = primaryRayFrom(cfg, gp, s, accW, true);
+        bool enter;
+        if (masks.covered) enter = enterMask;
+        else {
+          RayInv ri = makeRayInv(cfg.cam.pos, pr.d);
+          float tn;
+          enter = slab(ri, box.mn[0], box.mn[1], box.mn[2], box.mx[0], box.mx[1], box.mx[2], PT_FLT_MAX, tn);
+        }
+        Hit h; h.t = 0; h.u = 0; h.v = 0; h.tri = 0;
+        if (enter) { uint32_t cN = 0, cT = 0; active = traverse<false, true, false, PT_FUSE_OCTANTS>(sc, cfg.cam.pos, pr.d, cfg.eps, h, cN, cT); }
+        else culled++;
+        if (active) {
+          hitPos = cfg.cam.pos + pr.d * h.t;
+          vertexTables(tb, h.tri, h.u, h.v, normal, color, matTag);
+          g = pr.g; sampleIdx = pr.sampleIdx; hits++;
+        } else {
+          rec = f4(sampleSky(pr.d), 0.0f);                                              // rendering.d:480
+        }
+      }
+      if (__any(active)) shadeVertex<true, true, true>(cx, tb, active, hitPos, normal, color, matTag, 0u, g, gp, sampleIdx, 0u, 0u, &rec);
+      if (valid) {
+        // k_accumulate's addSample
+        V3 add = xyz(rec);
+        const uint32_t tag = f2u(rec.w);
+        if (tag) { const float4 m = tb.mat(tag - 1u); add = m.x * v3(m.y, m.z, m.w) + add; }
+        float4 b = sSum[threadIdx.x];
+        b.x += add.x; b.y += add.y; b.z += add.z; b.w += 1.0f;
+        sSum[threadIdx.x] = b;
+      }
+    }
+    if (valid) acc[gp] = sSum[threadIdx.x];
+  }
+  flushTraced(cx, true);
+  for (int off = 32; off > 0; off >>= 1) {
+    culled += __shfl_down(culled, off); nConst += __shfl_down(nConst, off); hits += __shfl_down(hits, off); mine += __shfl_down(mine, off);
+  }
+  if (lane == 0) {
+    if (culled) statAdd(wf.stats, STAT_RAYS_CULLED, (unsigned long long)culled);
+    if (nConst) statAdd(wf.stats, STAT_CONSTANT_SKY, (unsigned long long)nConst);
+    if (hits) {
+      statAdd(wf.stats, STAT_HITS, (unsigned long long)hits); statAdd(wf.stats, STAT_HITS_PRIMARY, (unsigned long long)hits);
+    }
+    if (mine > culled) statAdd(wf.stats, STAT_FUSED_PRIMARY, (unsigned long long)(mine - culled));     // view rays traced here
   }
 }
 
@@ -2070,6 +2194,13 @@ void launchSampleTraced(const LaunchCfg& lc, const SceneBox& box, const ViewMask
                         const PixMap& pm, const float4* acc, uint32_t nslots, const Wavefront& wf) {
   const uint32_t all = shadeTableBytes(sc) + (uint32_t)sc.ldsBytes;
   hipLaunchKernelGGL(k_sample_traced, dim3(PT_SAMPLE_GROUPS), dim3(PT_SAMPLE_THREADS), all, lc.stream, box, masks, sc, cfg, pm, acc, nslots, wf);
+}
+
+void launchPixelTraced(const LaunchCfg& lc, const SceneBox& box, const ViewMasks& masks, const DevScene& sc, const DevCfg& cfg,
+                       const PixMap& pm, float4* acc, const Wavefront& wf) {
+  const uint32_t all = shadeTableBytes(sc) + (uint32_t)sc.ldsBytes;
+  hipLaunchKernelGGL(k_pixel_traced, dim3(PT_SAMPLE_GROUPS), dim3(PT_SAMPLE_THREADS), all, lc.stream, box, masks, sc, cfg, pm, acc, wf);
+  if (wf.runPool) (void)hipMemsetAsync(wf.runPool, 0, PT_POOL_WORDS * sizeof(uint32_t), lc.stream);      // zero between launches
 }
 
 void launchAccumulate(const LaunchCfg& lc, const ViewMasks& masks, const DevCfg& cfg, const PixMap& pm, float4* acc,

@@ -50,7 +50,7 @@ def kind_of(name):
         return 'shade' if '<true' in name else 'shade_traced'
     return {'k_extend': 'extend', 'k_extend_refill': 'extend', 'k_connect': 'connect', 'k_occluded': 'occluded', 'k_shade': 'shade',
             'k_accumulate': 'accumulate', 'k_scan': 'other', 'k_raygen': 'raygen', 'k_raygen_extend': 'raygen_extend',
-            'k_shade_occluded': 'shade_occluded', 'k_sample_traced': 'sample_traced'}.get(base)
+            'k_shade_occluded': 'shade_occluded', 'k_sample_traced': 'sample_traced', 'k_pixel_traced': 'pixel_traced'}.get(base)
 
 
 def bench_line(path):

@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.PtConfig) == 4 * 6 + 12 * 3 + 4 * 2 + 4 * 8          # all 4-byte fields, no padding
     assert P.PIXEL_DTYPE.itemsize == 28 and P.MATERIAL_DTYPE.itemsize == 16   # rendering.d:24-37
     st = _lib.PtStats()
-    assert C.sizeof(st) == 23 * 8 + 11 * 8 + 11 * 8 + 8 + 6 * 4 + 8 + 8
+    assert C.sizeof(st) == 23 * 8 + 12 * 8 + 12 * 8 + 8 + 6 * 4 + 8 + 8
 
 
 def test_host_only_handle_fails_loudly_on_gpu_calls():

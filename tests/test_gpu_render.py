@@ -482,6 +482,37 @@ def test_samples_taken_from_the_common_pool_equal_the_workgroups_own_shares(requ
             assert getattr(sa, f) == getattr(sx, f), f
 
 
+@pytest.mark.parametrize('name,sky,W,H,spp', [('cornell-box', 0, 1280, 960, 9), ('cornell-box', 1, 1280, 960, 5), ('chest1', 1, 1280, 720, 7),
+                                              ('chest1', 1, 320, 200, 1), ('cornell-box', 0, 301, 77, 1)])
+def test_samples_added_up_in_registers_equal_the_recorded_ones(require_gpu, name, sky, W, H, spp):
+    """Mode 0 on the one-kernel-per-sample path, windows of at least 786432 pixels or one sample per pixel: a lane
+    renders the samples of one pixel one after the other and adds them to the pixel's sum in registers
+    (k_pixel_traced) -- no radiance record per sample, no accumulate launch.  Same bits and counters as the recorded
+    path (PT_FLAG_NO_PIXEL_SUMS) and as one launch per stage (PT_FLAG_NO_FUSE), over two calls (the second continues the
+    pixels' sample numbering), for whole frames, windows that are not whole tiles, and interleaved bands."""
+    out = []
+    for flags in (0, P.PT_FLAG_NO_PIXEL_SUMS, P.PT_FLAG_NO_FUSE, P.PT_FLAG_STATIC_RUNS):
+        pt = make_tracer(name, W, H, has_sky=sky, mode=0, seed=5, flags=flags | P.PT_FLAG_TIME_KERNELS)
+        pt.render_frame(spp)
+        pt.render_frame(1)
+        pt.render(W * 3 + 5, W * H - W * 7 - 11, spp)               # a window that starts and ends inside a row
+        pt.render_bands(4, 1, 3, spp)
+        out.append((pt.read_pixels(), pt.stats()))
+        pt.close()
+    (a, sa) = out[0]
+    k = dict(zip(P.PT_K_NAMES, sa.kernelLaunches))
+    # the two frames and (large frames, or one sample per pixel) the window and the bands; a third of a frame with
+    # several samples per pixel is rendered the recorded way
+    assert k['pixel_traced'] >= (3 if W * H >= 786432 or spp == 1 else 2) and sa.raysPrimaryInShade > 0
+    kb = dict(zip(P.PT_K_NAMES, out[1][1].kernelLaunches))
+    assert kb['pixel_traced'] == 0 and kb['sample_traced'] > 0 and kb['accumulate'] > 0
+    for x, sx in out[1:]:
+        assert np.array_equal(a['n'], x['n']) and np.array_equal(a['sum'].view(np.uint32), x['sum'].view(np.uint32))
+        for f in ('raysPrimary', 'raysLight', 'raysIndirect', 'raysOcclusion', 'raysCulled', 'hits', 'hitsPrimary', 'envEntries', 'samples',
+                  'samplesConstantSky'):
+            assert getattr(sa, f) == getattr(sx, f), f
+
+
 def test_wavefront_state_follows_the_path_the_scene_takes(require_gpu):
     """A handle whose scene takes the one-kernel-per-sample path keeps neither the view-ray queue nor the shadow queues.
     The same handle switched to the queued path (ptgpu_set_config), back again, and given a scene too large for that
