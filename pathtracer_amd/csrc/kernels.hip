@@ -880,9 +880,9 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend_refill(DevScene sc, DevCfg cfg, Pix
 #endif
 }
 
-// (The same scheme in k_connect and k_occluded was measured on the 10 M-triangle soup and dropped: 25.5 -> 27.1 ms and
-// 28.2 -> 28.3 ms per 4 spp.  Their rays start at scattered hit points, half of their node and triangle fetches miss
-// the L2, and the launches move 0.6-0.7 of the HBM peak: memory, not idle lanes, is what they wait for.)
+// (k_connect_refill and k_occluded_refill below are the same scheme for the shadow rays.  A first attempt at them,
+// made while the queues were still in launch-wide sample order, gained nothing; with the hit queue in ray order and
+// the queue handed out by XCD they take 16 % and 22 % off their launches on the 10 M-triangle soup.)
 
 // Raygen and the extend of the view rays in one traversal launch: a wave takes runs of 64 path slots (a pixel tile at
 // one sample number), decides each slot as k_raygen does (constant sky: nothing; not covered: sampleSky; covered: the
@@ -1125,6 +1125,130 @@ __global__ void PT_TRAVERSAL_BOUNDS k_occluded(DevScene sc, float eps, V3 sunRad
   for (int off = 32; off > 0; off >>= 1) nRays += __shfl_down(nRays, off);
   if ((threadIdx.x & 63) == 0 && nRays) statAdd(stats, STAT_RAYS_OCCL, (unsigned long long)nRays);
   flushCounts<COUNT>(stats, STAT_NODES_ANY, cN, cT);
+}
+
+// k_connect for scenes traversed from global memory, with lanes that take the next ray when theirs is decided.
+#ifndef PT_REFILL_CONNECT
+#define PT_REFILL_CONNECT 32
+#endif
+__global__ void PT_TRAVERSAL_BOUNDS k_connect_refill(DevScene sc, float eps, QMeta q, uint32_t segCap, const float4* __restrict__ shO,
+                                                     const float4* __restrict__ shD, const float4* __restrict__ shW,
+                                                     uint32_t* taskCounter, float area, float4* __restrict__ Lacc,
+                                                     unsigned long long* stats) {
+  __shared__ __align__(16) WorkPool pool;
+  initPool(&pool);
+  __syncthreads();
+  const uint32_t total = q.prefix[PT_SEGS];
+  if (blockIdx.x == 0 && threadIdx.x == 0) statAdd(stats, STAT_RAYS_LIGHT, (unsigned long long)total);
+  SegCursor cur; cur.seg = 0; cur.lo = 1; cur.hi = 0;
+  uint32_t e = 0, slot = 0; bool hasRay = false; float lightDistance = 0.0f;
+  LaneTrav t; idleTrav(t);
+  uint32_t stack[64];
+  WaveSupply sup;
+  for (;;) {
+    if (hasRay && !t.busy()) {
+      // the body of `if(distanceY > lightDistance - FloatEpsilon)`, rendering.d:416-425
+      if (t.found && t.h.t > lightDistance - eps) {
+        const float4 w = shW[e];
+        const float4 q0 = sc.nrm[3 * t.h.tri], q1 = sc.nrm[3 * t.h.tri + 1], q2 = sc.nrm[3 * t.h.tri + 2];
+        const V3 normalY = interpNormal(xyz(q0), xyz(q1), xyz(q2), t.h.u, t.h.v);
+        const float4 m = sc.mats[f2u(q0.w)];
+        const V3 Le = m.x * v3(m.y, m.z, m.w);
+        float G = w.w * dot(normalY, -t.d) / (lightDistance * lightDistance);
+        if (!(G > 0.0f)) G = 0.0f;
+        const V3 c = xyz(w) * Le * G * area;
+        float4 L = Lacc[slot];
+        L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z;
+        Lacc[slot] = L;
+      }
+      hasRay = false;
+    }
+    bool need = !hasRay;
+    while (sup.open && __any(need)) {
+      uint32_t j;
+      if (!sup.take(&pool, taskCounter, q, total, 0, need, j)) break;
+      if (j != PT_NONE) {
+        e = physIndexHint(q, j, sup.seg, segCap, cur);
+        const float4 ro = shO[e], rd = shD[e];
+        slot = f2u(ro.w); lightDistance = rd.w;
+        startTrav(sc, t, xyz(ro), xyz(rd));
+        hasRay = true; need = false;
+      }
+    }
+    if (!__any(hasRay)) break;
+    advanceTrav<false>(sc, t, stack, eps, sup.open ? (uint32_t)PT_REFILL_CONNECT : 1u);
+  }
+}
+
+// k_occluded for scenes traversed from global memory, with lanes that take the next ray when theirs is decided (the
+// scheme of k_extend_refill): a lane works through its entry's sun ray, then its sky ray, then the next entry of the
+// wave's chunk; whenever fewer than PT_REFILL_ANY lanes are traversing, the decided rays are written out and the free
+// lanes supplied.  An entry's L is stored once, when its last ray is decided, in the order sun, sky.
+#ifndef PT_REFILL_ANY
+#define PT_REFILL_ANY 32
+#endif
+__global__ void PT_TRAVERSAL_BOUNDS k_occluded_refill(DevScene sc, float eps, V3 sunRadiance, V3 skyRadiance, int direct, QMeta q,
+                                                      uint32_t segCap, const float4* __restrict__ shO, const float4* __restrict__ shD,
+                                                      const float4* __restrict__ shW, const float4* __restrict__ shX,
+                                                      uint32_t* taskCounter, float4* __restrict__ Lacc, unsigned long long* stats) {
+  __shared__ __align__(16) WorkPool pool;
+  initPool(&pool);
+  __syncthreads();
+  const uint32_t total = q.prefix[PT_SEGS];
+  if (blockIdx.x == 0 && threadIdx.x == 0) statAdd(stats, STAT_ENV_ENTRIES, (unsigned long long)total);
+  SegCursor cur; cur.seg = 0; cur.lo = 1; cur.hi = 0;
+  uint32_t nRays = 0;
+  // the lane's entry: where it lies, what is still to be traced, what got through, the cosines its radiance is weighted with
+  uint32_t e = 0, slot = 0; bool haveEntry = false, skyTodo = false, onSky = false, vSun = false, vSky = false, tracing = false;
+  float sSun = 0.0f, sSky = 0.0f;
+  LaneTrav t; idleTrav(t);
+  uint32_t stack[64];
+  WaveSupply sup;
+  for (;;) {
+    // lanes whose ray is decided: note the answer, go on with the entry's sky ray or close the entry
+    if (tracing && !t.busy()) {
+      if (onSky) vSky = !t.found; else vSun = !t.found;
+      tracing = false;
+      if (!onSky && skyTodo) {
+        const float4 b = shW[e];
+        onSky = true; skyTodo = false; tracing = true;
+        startTrav(sc, t, t.o, xyz(b));
+      }
+    }
+    auto closeEntry = [&]() {
+      if (direct || vSun || vSky) {
+        const float4 x = shX[e];
+        V3 Tw; float4 L;
+        if (direct) { V3 color = xyz(x); Tw = v3(1, 1, 1) * (PT_BRDF * color); L = make_float4(0.0f, 0.0f, 0.0f, x.w); }
+        else { Tw = xyz(x); L = Lacc[slot]; }
+        if (vSun) { V3 c = Tw * sunRadiance * sSun; L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; }
+        if (vSky) { V3 c = Tw * skyRadiance * sSky; L.x = L.x + c.x; L.y = L.y + c.y; L.z = L.z + c.z; }
+        Lacc[slot] = L;
+      }
+      haveEntry = false;
+    };
+    if (haveEntry && !tracing) closeEntry();
+    bool need = !haveEntry;
+    while (sup.open && __any(need)) {
+      uint32_t j;
+      if (!sup.take(&pool, taskCounter, q, total, 0, need, j)) break;
+      if (j != PT_NONE) {
+        e = physIndexHint(q, j, sup.seg, segCap, cur);
+        const float4 ro = shO[e], a = shD[e], b = shW[e];
+        const bool eSun = a.x != 0.0f || a.y != 0.0f || a.z != 0.0f, eSky = b.x != 0.0f || b.y != 0.0f || b.z != 0.0f;
+        nRays += (eSun ? 1u : 0u) + (eSky ? 1u : 0u);
+        slot = f2u(ro.w); sSun = a.w; sSky = b.w; vSun = false; vSky = false; haveEntry = true;
+        if (eSun) { onSky = false; skyTodo = eSky; tracing = true; startTrav(sc, t, xyz(ro), xyz(a)); }
+        else if (eSky) { onSky = true; skyTodo = false; tracing = true; startTrav(sc, t, xyz(ro), xyz(b)); }
+        else closeEntry();                                     // (shade emits no such entry; kept for safety)
+        need = !haveEntry;
+      }
+    }
+    if (!__any(tracing)) break;
+    advanceTrav<true>(sc, t, stack, eps, sup.open ? (uint32_t)PT_REFILL_ANY : 1u);
+  }
+  for (int off = 32; off > 0; off >>= 1) nRays += __shfl_down(nRays, off);
+  if ((threadIdx.x & 63) == 0 && nRays) statAdd(stats, STAT_RAYS_OCCL, (unsigned long long)nRays);
 }
 
 // ------------------------------------------------------------------------------------------------ shade
@@ -2139,6 +2263,12 @@ void launchExtend(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, co
 void launchConnect(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, float area) {
   Geo g = traversalGeo(lc, sc, wf.capQueue);
   size_t e = (size_t)kind * wf.capQueue;
+  if (!sc.ldsBytes && !lc.countVisits && PT_REFILL_CONNECT) {
+    hipLaunchKernelGGL(k_connect_refill, g.grid, g.block, 0, lc.stream, sc, cfg.eps, wf.sh[kind], wf.capQueue / PT_SEGS,
+                       (const float4*)(wf.shO + e), (const float4*)(wf.shD + e), (const float4*)(wf.shW + e),
+                       wf.taskCounters + (1 + kind) * PT_TASK_PARTS, area, wf.Lacc, wf.stats);
+    return;
+  }
   PT_DISPATCH_LC(k_connect, sc, cfg.eps, wf.sh[kind], wf.capQueue / PT_SEGS, (const float4*)(wf.shO + e), (const float4*)(wf.shD + e),
                  (const float4*)(wf.shW + e), wf.taskCounters + (1 + kind) * PT_TASK_PARTS, area, wf.Lacc, wf.stats);
 }
@@ -2146,6 +2276,13 @@ void launchConnect(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, c
 void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, bool primary) {
   Geo g = traversalGeo(lc, sc, wf.capQueue);
   size_t e = (size_t)kind * wf.capQueue;
+  if (!sc.ldsBytes && !lc.countVisits && PT_REFILL_ANY) {
+    hipLaunchKernelGGL(k_occluded_refill, g.grid, g.block, 0, lc.stream, sc, cfg.eps, cfg.sunRadiance, cfg.skyRadiance,
+                       envDirect(cfg, sc, primary) ? 1 : 0, wf.sh[kind], wf.capQueue / PT_SEGS, (const float4*)(wf.shO + e),
+                       (const float4*)(wf.shD + e), (const float4*)(wf.shW + e), (const float4*)wf.shX,
+                       wf.taskCounters + (1 + kind) * PT_TASK_PARTS, wf.Lacc, wf.stats);
+    return;
+  }
   PT_DISPATCH_LC(k_occluded, sc, cfg.eps, cfg.sunRadiance, cfg.skyRadiance, envDirect(cfg, sc, primary) ? 1 : 0, wf.sh[kind],
                  wf.capQueue / PT_SEGS, (const float4*)(wf.shO + e), (const float4*)(wf.shD + e), (const float4*)(wf.shW + e),
                  (const float4*)wf.shX, wf.taskCounters + (1 + kind) * PT_TASK_PARTS, wf.Lacc, wf.stats);
