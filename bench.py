@@ -100,7 +100,7 @@ def profile_json(workload):
 
 
 # kernel kind (PtStats.kernelMs index, pathtracer_amd.PT_K_NAMES) -> the kernel it times
-KERNEL_OF = {'extend': 'k_extend / k_extend_refill', 'connect': 'k_connect', 'occluded': 'k_occluded', 'shade': 'k_shade',
+KERNEL_OF = {'extend': 'k_extend / k_extend_refill', 'connect': 'k_connect / k_connect_refill', 'occluded': 'k_occluded / k_occluded_refill', 'shade': 'k_shade',
              'accumulate': 'k_accumulate', 'other': 'k_scan', 'raygen': 'k_raygen', 'raygen_extend': 'k_raygen_extend',
              'shade_occluded': 'k_shade_occluded', 'shade_traced': 'k_shade_traced<false>', 'sample_traced': 'k_sample_traced', 'pixel_traced': 'k_pixel_traced'}
 
