@@ -69,17 +69,28 @@ struct DevCfg {               // PtConfig + camera as the kernels need them
 // tileW x (64/tileW) block of pixels (coherent rays per wave; needs whole rows) -- and q to a frame pixel:
 //   offset + lpBase + q                                    (bandPix == 0: contiguous window)
 //   (bandFirst + j*bandStride)*bandPix + r, j = (lpBase+q) / bandPix, r = (lpBase+q) % bandPix   (band set)
+// Tiles are numbered strip by strip: vertical strips of stripW tiles, row-major inside a strip (stripW == 0: row-major
+// over the whole width).  Consecutive runs of slots -- what the waves of a launch, and the workgroups that share an
+// L2, have in flight at a time -- then cover a compact block of pixels instead of a band across the frame, so the
+// rays in flight meet in a smaller part of a scene that is traversed from global memory.  The last strip takes what
+// is left of the width (lastW tiles; nFull strips are full).
 struct PixMap {
   uint32_t offset, bandPix, bandFirst, bandStride, lpBase, npix, k;
   uint32_t tileW, tilesPerRow;      // tile shape and tiles per row of the frame
-  FastDiv divNpix, divBand, divTilesPerRow;
+  uint32_t stripW, stripTiles, nFull, lastW;      // stripTiles = stripW * rows of tiles in the batch
+  FastDiv divNpix, divBand, divTilesPerRow, divStripTiles, divStripW, divLastW;
 };
 
 PT_HD uint32_t mapPixel(const PixMap& pm, uint32_t W, uint32_t lp) {
   uint32_t q = lp;
   if (pm.tileW) {
     uint32_t tile = lp >> 6, in = lp & 63u;
-    uint32_t tr = fdiv(pm.divTilesPerRow, tile), tc = tile - tr * pm.tilesPerRow;
+    uint32_t tr, tc;
+    if (pm.stripW) {
+      uint32_t strip = fdiv(pm.divStripTiles, tile);
+      if (strip >= pm.nFull) { uint32_t t = tile - pm.nFull * pm.stripTiles; tr = fdiv(pm.divLastW, t); tc = pm.nFull * pm.stripW + (t - tr * pm.lastW); }
+      else { uint32_t t = tile - strip * pm.stripTiles; tr = fdiv(pm.divStripW, t); tc = strip * pm.stripW + (t - tr * pm.stripW); }
+    } else { tr = fdiv(pm.divTilesPerRow, tile); tc = tile - tr * pm.tilesPerRow; }
     uint32_t tx, ty;
     if (pm.tileW == 8) { tx = in & 7u; ty = in >> 3; } else { tx = in & 15u; ty = in >> 4; }
     uint32_t th = 64u / pm.tileW;
