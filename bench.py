@@ -128,12 +128,12 @@ def kernel_work(kind, st, visits, npix_launches):
         units = H - Hp
         closest, anyh = (fl - wl) + (fi - wi), fo - wo
         later = max(0, units - st.chainHitsFromSample)
-        rec = units * 32.0 + later * (32.0 + 24.0 + 24.0)
+        rec = units * (32.0 + 16.0) + later * (32.0 + 8.0 + 8.0)
         return units, rec, closest * nc + anyh * na, closest * tc + anyh * ta, \
-            '32 B hit record read per vertex; per hit of a later bounce 32 B record + 24 B throughput and generator written and read back; the 32 B read-modify-write of a chain\'s radiance is not counted'
+            '32 B hit record read + 16 B radiance record written per vertex; per hit of a later bounce 32 B hit record written and 8 B of generator state written and read back'
     if kind == 'accumulate':
-        rec = (S - const) * 16.0 + npix_launches * 32.0 + st.chainHitsFromSample * 16.0
-        return npix_launches, rec, 0.0, 0.0, '16 B radiance record per sample outside constant sky, 16 B per chain record that holds anything, 32 B of accumulator per pixel and launch'
+        rec = (S - const) * 16.0 + npix_launches * 32.0 + (H - Hp) * 32.0
+        return npix_launches, rec, 0.0, 0.0, '16 B radiance record per sample outside constant sky, 16 B per chain vertex read twice (the chain\'s length, then the fold from its end), 32 B of accumulator per pixel and launch'
     if kind == 'raygen_extend':
         traced = S - st.raysCulled
         rec = (S - const) * 4.0 + (S - const - Hp) * 16.0 + Hp * 32.0
@@ -160,7 +160,7 @@ def kernel_work(kind, st, visits, npix_launches):
     if kind == 'shade':
         units = H - (Hp if fp else 0) - (0 if not fi else H - Hp)
         rec = units * 32.0 + (st.raysLight - fl) * 48.0 + (st.envEntries if not fo else 0) * 64.0 + (st.raysIndirect - fi) * 32.0
-        return units, rec, 0.0, 0.0, '32 B hit record read per vertex; 48 B per light-sample ray, 64 B per sun/sky entry, 32 B per continuation ray written'
+        return units, rec, 0.0, 0.0, '32 B hit record read per vertex; 48 B per light-sample ray, 64 B per sun/sky entry, 32 B per continuation ray written (the 16 B radiance record a vertex starts with is left out where the sun / sky kernel writes it)'
     return None
 
 
@@ -260,10 +260,9 @@ def measure(P, torch, dist, multigpu, name, args, rank, world, local_rank, rehea
     # set_camera also builds the view-ray masks on the GPU, whose cost is reported.  --no-visits (the counter passes of
     # scripts/profile_workload.sh) leaves it out, so that every launch the profiler sees belongs to the timed region ----
     if args.no_visits:
-        pt.render(0, 64, 1); pt.synchronize()              # builds the masks
+        pt.coverage_mask()                                 # builds the masks without launching a kernel of the render path
         cst = pt.stats()
         visits = dict(nodes_closest=0.0, tris_closest=0.0, nodes_any=0.0, tris_any=0.0)
-        pt.clear_pixels()
     else:
         pt.set_config(flags=P.PT_FLAG_COUNT_VISITS | bvh_flag)
         pt.reset_stats()

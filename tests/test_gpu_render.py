@@ -82,6 +82,25 @@ def test_image_equals_oracle_with_same_streams_mode1(require_gpu, name, flats):
     assert np.isfinite(got['sum']).all() and (got['sum'] >= (-0.0036 * 16 * 6 if sky else 0)).all()
 
 
+@pytest.mark.parametrize('name,sky,depth,chains,rr', [('cornell-box', 1, 2, 3, 0.9), ('cornell-box', 0, 7, 8, 0.8), ('teapot', 1, 1, 2, 0.95),
+                                                     ('teapot', 1, 6, 6, 0.5), ('chest1', 1, 3, 1, 0.7)])
+def test_chains_of_other_depths_and_counts_equal_the_oracle(require_gpu, name, sky, depth, chains, rr, flats):
+    """The records of a chain are laid out by bounce round and chain (kernels.h: Wavefront::Lacc), so their number
+    follows maxDepth and numIndirect: depth caps from 1 to 7, one to eight chains, other roulette probabilities --
+    same rays as the oracle (counts) and the same bits, on the kernels that trace their own rays (cornell-box, chest1)
+    and on the queued ones (teapot)."""
+    W, H, spp = 48, 40, 6
+    pt = make_tracer(name, W, H, has_sky=sky, mode=1, seed=77, max_depth=depth, n_indirect=chains, rr=rr)
+    o = make_oracle(flats[name], name, W, H, has_sky=bool(sky), mode=1, seed=77, max_depth=depth, n_indirect=chains, rr=rr)
+    pt.render_frame(spp); pt.render_frame(2)
+    got = pt.read_pixels()
+    ref = oracle_py.new_pixels(W * H); _, c1 = o.render_keyed(ref, 0, spp, nthreads=8); _, c2 = o.render_keyed(ref, 0, 2, nthreads=8)
+    st = pt.stats()
+    assert int(st.raysPrimary + st.raysLight + st.raysIndirect) == int(c1[0] + c2[0]) and int(st.raysOcclusion) == int(c1[1] + c2[1])
+    assert st.raysIndirect > 0
+    assert np.array_equal(got['n'], ref['n']) and np.array_equal(got['sum'].view(np.uint32), ref['sum'].view(np.uint32))
+
+
 @pytest.mark.parametrize('name,mode,spp', [('cornell-box', 0, 256), ('teapot', 0, 64), ('chest1', 1, 64)])
 def test_converged_image_vs_reference_shaped_oracle(require_gpu, name, mode, spp, flats):
     """Equal-spp comparison with the bands + Mt19937 + sphere-tree renderer: within Monte Carlo noise."""
