@@ -1813,12 +1813,12 @@ __global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_SAMPLE_WAVES) k_sample_t
 // k_accumulate would (emissive * color + L for a hit, sampleSky for a miss, the sky constant for a constant-sky
 // pixel; rendering.d:477-482), in sample order, so the sums are the same bits.  No radiance record is written or
 // read back (32 B of HBM traffic per sample), no accumulate launch, and no state per sample: the batch is the whole
-// window whatever its size.  Columns are dealt out one at a time through the pool counters (wf.runPool; zero at
-// launch, the host clears them behind the launch), or in turn when there is no pool -- a column with all its samples
-// is a twentieth of a wave's share of a 4K frame, and pieces of four columns cost 20 % (cornell 4K 64 spp: 32.2 ms
-// against 26.8; with the sums in LDS 26.5; the recorded path 28.7).
-#ifndef PT_PIXEL_CHUNK
-#define PT_PIXEL_CHUNK 1
+// window whatever its size.  Columns are dealt out one at a time (below) -- a column with all its samples is a
+// twentieth of a wave's share of a 4K frame, and pieces of four columns cost 20 % (cornell 4K 64 spp: 32.2 ms against
+// 26.8; with the sums in LDS 26.5; the recorded path 28.7).  The pool counters (wf.runPool) are zero at launch; the
+// host clears them behind the launch.
+#ifndef PT_PIXEL_POOL_FROM
+#define PT_PIXEL_POOL_FROM 32      // columns per workgroup from which a launch pools them
 #endif
 __global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_SAMPLE_WAVES) k_pixel_traced(SceneBox box, ViewMasks masks, DevScene sc, DevCfg cfg, PixMap pm,
                                                                   float4* __restrict__ acc, Wavefront wf) {
@@ -1832,29 +1832,37 @@ __global__ void __launch_bounds__(PT_SAMPLE_THREADS, PT_SAMPLE_WAVES) k_pixel_tr
   // the pixels' sums wait in LDS while a sample is worked out (four registers less across the sample's code)
   __shared__ float4 sSum[PT_SAMPLE_THREADS];
   const uint32_t columns = (pm.npix + 63u) >> 6, lane = threadIdx.x & 63u;
-  const uint32_t wavesPerGroup = blockDim.x >> 6, waveId = blockIdx.x * wavesPerGroup + (threadIdx.x >> 6), numWaves = gridDim.x * wavesPerGroup;
   uint32_t culled = 0, nConst = 0, hits = 0, mine = 0;
-  uint32_t pending = 0, pendingCol = 0, usedUp = 0, turn = 0;
+  // Who renders which column.  A launch with few columns per workgroup deals column c to workgroup c % gridDim.x, and a
+  // workgroup's columns to whichever of its waves is free (a counter in LDS): no global atomic -- in a 320 x 240 pass
+  // the waves' takes from the pool, and the eight probes with which every one of them finds it empty, cost as much as
+  // the pass itself (0.133 ms against 0.076).  A larger launch pools all its columns: the waves of all workgroups take
+  // them one at a time from the PT_POOL_COUNTERS counters (each deals out every PT_POOL_COUNTERS-th column), and a
+  // workgroup remembers the counters it has found used up.
+  __shared__ uint32_t sNextCol, sUsedUp;
+  if (threadIdx.x == 0) { sNextCol = 0; sUsedUp = 0; }
+  __syncthreads();
+  const uint32_t G = gridDim.x, share = (columns + G - 1) / G;
+  const bool pooled = wf.runPool && share >= PT_PIXEL_POOL_FROM;
   for (;;) {
     uint32_t col = PT_NONE;
-    if (!wf.runPool) { col = waveId + turn * numWaves; turn++; if (col >= columns) break; }
-    else if (pending) { col = pendingCol; pendingCol += PT_POOL_COUNTERS; pending--; }
-    else {
-      uint32_t got = 0;
-      if (lane == 0) {
-        while (usedUp < PT_POOL_COUNTERS) {
+    if (lane == 0) {
+      if (!pooled) {
+        const uint32_t k = atomicAdd(&sNextCol, 1u);
+        if (k < share && blockIdx.x + G * k < columns) col = blockIdx.x + G * k;
+      } else {
+        for (;;) {
+          const uint32_t usedUp = atomicAdd(&sUsedUp, 0u);
+          if (usedUp >= PT_POOL_COUNTERS) break;
           const uint32_t c = (blockIdx.x + usedUp) % PT_POOL_COUNTERS;
-          const uint32_t r = c + PT_POOL_COUNTERS * atomicAdd(&wf.runPool[c * PT_POOL_STRIDE], (uint32_t)PT_PIXEL_CHUNK);
-          if (r < columns) { col = r; got = min((uint32_t)PT_PIXEL_CHUNK, (columns - r + PT_POOL_COUNTERS - 1) / PT_POOL_COUNTERS); break; }
-          usedUp++;
+          const uint32_t r = c + PT_POOL_COUNTERS * atomicAdd(&wf.runPool[c * PT_POOL_STRIDE], 1u);
+          if (r < columns) { col = r; break; }
+          atomicMax(&sUsedUp, usedUp + 1u);
         }
       }
-      got = (uint32_t)__builtin_amdgcn_readfirstlane(got);
-      usedUp = (uint32_t)__builtin_amdgcn_readfirstlane(usedUp);
-      if (!got) break;
-      col = (uint32_t)__builtin_amdgcn_readfirstlane(col);
-      pending = got - 1; pendingCol = col + PT_POOL_COUNTERS;
     }
+    col = (uint32_t)__builtin_amdgcn_readfirstlane(col);
+    if (col == PT_NONE) break;
     const uint32_t lp = (col << 6) + lane;
     const bool valid = lp < pm.npix;
     const uint32_t gp = mapPixel(pm, cfg.W, valid ? lp : 0u);
