@@ -236,6 +236,34 @@ def test_band_and_sample_splits_reassemble_bit_identically(require_gpu):
         assert (got['n'] == 4).all() and np.array_equal(got['sum'].view(np.uint32), acc.view(np.uint32))
 
 
+@pytest.mark.parametrize('mode', [0, 1])
+def test_tile_strips_of_a_scene_in_global_memory_do_not_change_the_image(require_gpu, mode):
+    """A scene traversed from global memory numbers its pixel tiles by vertical strips of 32 tiles (frames wider than
+    256 pixels), and its shadow kernels hand lanes the next ray.  Whole frames, windows that are not whole rows, bands
+    of a frame whose width is not a multiple of the strip (a narrower last strip) and small batches (several chunks per
+    frame): the same bits as the same scene rendered from LDS, where tiles are numbered row by row."""
+    fl = soup(1200, seed=31, size=14.0)
+    W, H, spp = 808, 96, 3                                                # 101 tiles per row: three strips of 32 and one of 5
+    cam = P.Camera(30.0, H / W).setTransform((250, 180, 160), (0, 0, 0), (0, 0, 1))
+    out = []
+    for flags, slots in ((0, 0), (P.PT_FLAG_NO_LDS_SCENE, 0), (P.PT_FLAG_NO_LDS_SCENE, 65536)):
+        pt = P.PathTracer(W, H, has_sky=1, mode=mode, seed=12, max_depth=2, flags=flags, batch_slots=slots)
+        pt.upload_scene(fl['v'], fl['n'], fl['mat_idx'], fl['materials']); pt.set_camera(cam)
+        assert pt.stats().sceneInLds == (0 if flags else 1) and pt.stats().numLightGroups >= 1
+        pt.render_frame(spp)
+        pt.render(W * 5 + 3, W * 40 + 11, 2)
+        pt.render_bands(4, 1, 2, 2)
+        pt.render_bands(8, 0, 3, 1)
+        out.append((pt.read_pixels(), pt.stats()))
+        pt.close()
+    (a, sa) = out[0]
+    assert a['n'].max() == spp + 2 + 2 + 1
+    for x, sx in out[1:]:
+        assert np.array_equal(a['n'], x['n']) and np.array_equal(a['sum'].view(np.uint32), x['sum'].view(np.uint32))
+        for f in ('raysPrimary', 'raysLight', 'raysIndirect', 'raysOcclusion', 'hits', 'hitsPrimary', 'envEntries', 'samples'):
+            assert getattr(sa, f) == getattr(sx, f), f
+
+
 def test_pixel_checkpoint_roundtrip_and_resume(require_gpu, tmp_path):
     """main.d:227-234, 333-340: raw Pixel[] dump and restore; resuming continues the same sample sequence."""
     name, W, H = 'cornell-box', 64, 40
