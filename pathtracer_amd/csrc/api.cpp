@@ -126,7 +126,10 @@ struct PtHandle {
   DevBuf dMask, dSkyMask; bool maskDirty = true, maskUsable = false;
   DevBuf dVerts, dMaskRows, dMaskBig, dMaskFlags; double sceneScale = 0.0;   // for the GPU build of the masks (mask_gpu.h)
   DevBuf dTex; bool texDirty = true;   // TriangleData.tex in input order, uploaded at the first texcoord trace
-  ViewMasks masks() const { return maskUsable ? ViewMasks{dMask.as<uint32_t>(), dSkyMask.as<uint32_t>()} : ViewMasks{nullptr, nullptr}; }
+  ViewMasks masks() const { return maskUsable ? ViewMasks{dMask.as<uint32_t>(), dSkyMask.as<uint32_t>(), nullptr} : ViewMasks{nullptr, nullptr, nullptr}; }
+  // which columns of the current batch geometry have anything but constant sky (ViewMasks::activeCols): built on the
+  // stream when the geometry or the masks change
+  DevBuf dActiveCols; PixMap colKey{}; uint64_t colMaskGen = 0, maskGen = 0; bool colValid = false;
   DevBuf bMetaDesc; std::vector<QMeta> metas;     // queue descriptors: device copy and host copy, stage-major
   Wavefront wf{}; uint32_t wfKinds = 0, wfRounds = 0; bool wfLean = false;
   // ptgpu_render_noalloc: address of the static scratch array on this handle's device, and the host copy of the
@@ -481,6 +484,8 @@ bool pixelSums(const PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, uint64_
   return pixelSumsPay(npix, spp);
 }
 
+const uint32_t* activeColumns(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, const PixMap& pm, const ViewMasks& masks);
+
 void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, const WfState& ws) {
   Wavefront wf = ws.wf;
   wf.divCap = makeFastDiv(wf.capSlots); wf.round = 0;
@@ -542,7 +547,9 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
     bind(1);
     wf.hitOutA = pairA[0]; wf.hitOutB = pairB[0];
     if (dc.mode == 1) wf.rayOut = ws.hostMetas[(size_t)2 * perStage];
-    { Timed t(h, PT_K_SAMPLE_TRACED); launchSampleTraced(lc, h->box, ws.masks, h->dsc, dc, pm, h->acc, nslots, wf); t.done(); }
+    ViewMasks vm = ws.masks;
+    if (ws.hostMetas == h->metas.data()) vm.activeCols = activeColumns(h, dc, lc, pm, ws.masks);      // (not for a caller's state: it may allocate)
+    { Timed t(h, PT_K_SAMPLE_TRACED); launchSampleTraced(lc, h->box, vm, h->dsc, dc, pm, h->acc, nslots, wf); t.done(); }
     if (dc.mode == 1) fusedStage(2, false);                // one launch goes through all bounce rounds
     { Timed t(h, PT_K_ACCUM); launchAccumulate(lc, ws.masks, dc, pm, h->acc, wf, h->dsc); t.done(); }
     HIPCHECK(hipGetLastError());
@@ -613,6 +620,21 @@ void chooseTiling(PixMap& pm, uint32_t W, bool wholeRows, bool strips) {
     pm.nFull = pm.tilesPerRow / pm.stripW; pm.lastW = std::max(1u, pm.tilesPerRow - pm.nFull * pm.stripW);
   }
   pm.divStripTiles = makeFastDiv(pm.stripTiles); pm.divStripW = makeFastDiv(std::max(1u, pm.stripW)); pm.divLastW = makeFastDiv(pm.lastW);
+  pm.columns = pm.npix % 64u == 0 ? pm.npix / 64u : 0u; pm.divColumns = makeFastDiv(std::max(1u, pm.columns));
+}
+
+// The bitmap of the batch's columns that hold anything but constant sky, for the whole-sample kernel (kernels.h:
+// ViewMasks::activeCols): built on the handle's stream when the batch geometry or the masks have changed since the
+// last batch; a frame rendered in batches of the same pixels builds it once.
+const uint32_t* activeColumns(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, const PixMap& pm, const ViewMasks& masks) {
+  if (!masks.constantSky || !pm.columns) return nullptr;
+  PixMap key = pm; key.k = 0;
+  if (!h->colValid || h->colMaskGen != h->maskGen || std::memcmp(&key, &h->colKey, sizeof(PixMap)) != 0) {
+    h->dActiveCols.alloc(((size_t)pm.columns + 31) / 32 * 4);
+    launchActiveColumns(lc, masks, dc, pm, h->dActiveCols.as<uint32_t>());
+    h->colKey = key; h->colMaskGen = h->maskGen; h->colValid = true;
+  }
+  return h->dActiveCols.as<uint32_t>();
 }
 
 // The view-ray masks for the current scene and camera, built on the GPU (mask_gpu.h) on the handle's stream; the call
@@ -631,7 +653,7 @@ void buildMasks(PtHandle* h) {
                                   h->dSkyMask.as<uint32_t>(), &usable));
     h->maskUsable = usable;
   }
-  h->maskDirty = false;
+  h->maskDirty = false; h->maskGen++;
   h->st.maskBuildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tMask).count();
 }
 
@@ -997,7 +1019,7 @@ int ptgpu_render_noalloc(PtHandle* h, uint32_t pixelOffset, uint32_t pixelCount,
     ws.hostMetas = h->metasNoAlloc.data(); ws.devMetas = (const QMeta*)(base + L.desc);
     // masks built for the current scene and camera are used; none is built here (that would allocate): the view rays
     // are then culled by the scene's bounding box, which gives the same image
-    ws.masks = (!h->maskDirty && h->maskUsable) ? h->masks() : ViewMasks{nullptr, nullptr};
+    ws.masks = (!h->maskDirty && h->maskUsable) ? h->masks() : ViewMasks{nullptr, nullptr, nullptr};
     // one call at a time per GPU works on the array: this one starts behind the last kernel of the previous one (any
     // handle, any stream of this device) and the next one behind this one's.  Under a stream capture the order is the
     // capturing caller's to give.

@@ -53,7 +53,10 @@ struct SceneBox { float mn[3], mx[3]; };
 //   covered      some triangle's screen rectangle reaches the pixel: its view rays are traced
 //   constantSky  not covered and every sample of the pixel misses sampleSky's sun disc: each sample's radiance is
 //                the same constant, raygen skips the slot and accumulate adds the constant without reading it
-struct ViewMasks { const uint32_t* covered; const uint32_t* constantSky; };
+//   activeCols   per batch geometry (PixMap), or null: bit c says that column c of the batch -- local pixels 64 c ..
+//                64 c + 63, the pixels of a run of 64 path slots -- has a pixel that is NOT constant sky; a run of a
+//                column without one is skipped before anything is worked out per lane (launchActiveColumns)
+struct ViewMasks { const uint32_t* covered; const uint32_t* constantSky; const uint32_t* activeCols; };
 
 struct DevCfg {               // PtConfig + camera as the kernels need them
   uint32_t W, H, mode, hasSky, hasLights;
@@ -78,7 +81,8 @@ struct PixMap {
   uint32_t offset, bandPix, bandFirst, bandStride, lpBase, npix, k;
   uint32_t tileW, tilesPerRow;      // tile shape and tiles per row of the frame
   uint32_t stripW, stripTiles, nFull, lastW;      // stripTiles = stripW * rows of tiles in the batch
-  FastDiv divNpix, divBand, divTilesPerRow, divStripTiles, divStripW, divLastW;
+  uint32_t columns;                               // npix / 64 when that is whole (run r is column r % columns), else 0
+  FastDiv divNpix, divBand, divTilesPerRow, divStripTiles, divStripW, divLastW, divColumns;
 };
 
 PT_HD uint32_t mapPixel(const PixMap& pm, uint32_t W, uint32_t lp) {
@@ -249,6 +253,8 @@ void launchPixelTraced(const LaunchCfg& lc, const SceneBox& box, const ViewMasks
 // pixels are the units of work, and a wave walks a column's samples one after the other, so there have to be enough
 // columns for the waves of the chip -- or one sample each, where a column is no more work than a run.
 inline bool pixelSumsPay(uint64_t npix, uint32_t spp) { return spp == 1 || npix >= 64ull * 12288ull; }
+// bits[c >> 5] bit c & 31 = column c of pm has a pixel outside masks.constantSky (pm.columns columns; bits are cleared first)
+void launchActiveColumns(const LaunchCfg& lc, const ViewMasks& masks, const DevCfg& cfg, const PixMap& pm, uint32_t* bits);
 void launchAccumulate(const LaunchCfg& lc, const ViewMasks& masks, const DevCfg& cfg, const PixMap& pm, float4* acc,
                       const Wavefront& wf, const DevScene& sc);
 
