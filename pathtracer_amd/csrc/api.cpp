@@ -560,7 +560,9 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
   const bool rayExt = !wf.fuse && h->dsc.ldsBytes && !lc.countVisits && !(h->cfg.flags & PT_FLAG_NO_FUSE);
   if (rayExt) {
     bind(1);
-    { Timed t(h, PT_K_RAYGEN_EXTEND); launchRaygenExtend(lc, h->box, ws.masks, h->dsc, dc, pm, h->acc, nslots, wf); t.done(); }
+    ViewMasks vm = ws.masks;
+    if (ws.hostMetas == h->metas.data()) vm.activeCols = activeColumns(h, dc, lc, pm, ws.masks);
+    { Timed t(h, PT_K_RAYGEN_EXTEND); launchRaygenExtend(lc, h->box, vm, h->dsc, dc, pm, h->acc, nslots, wf); t.done(); }
     scan((size_t)perStage, 1);
     if (dc.mode == 0 && envDirect(dc, h->dsc, true)) {
       { Timed t(h, PT_K_SHADE_OCCLUDED); launchShadeOccluded(lc, h->dsc, dc, pm, h->acc, wf); t.done(); }

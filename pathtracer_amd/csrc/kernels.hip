@@ -937,6 +937,10 @@ __global__ void PT_TRAVERSAL_BOUNDS k_raygen_extend(SceneBox box, ViewMasks mask
   const uint32_t outBase = segFirst * segCapOut, outLimit = (segLast - segFirst) * segCapOut;
   uint32_t culled = 0, nConst = 0, cN = 0, cT = 0, begin;
   while (nextSlots(&pool, wf.taskCounters + (PT_TASK_COUNTERS - 1) * PT_TASK_PARTS, nslots, outLimit, begin)) {
+    if (masks.activeCols && pm.columns) {            // a run of a column of constant sky: counted, nothing else (see k_sample_traced)
+      const uint32_t run = begin >> 6, col = run - fdiv(pm.divColumns, run) * pm.columns;
+      if (!((masks.activeCols[col >> 5] >> (col & 31u)) & 1u)) { culled++; nConst++; continue; }
+    }
     const uint32_t i = begin + (threadIdx.x & 63u);
     const bool valid = i < nslots;
     uint32_t s, gp = slotPixel(cfg, pm, valid ? i : 0u, s);
