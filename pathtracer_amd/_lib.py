@@ -10,6 +10,7 @@ PT_OK, PT_E_INVALID, PT_E_STATE, PT_E_DEVICE, PT_E_IO, PT_E_NOMEM = 0, -1, -2, -
 PT_FLAG_COUNT_VISITS, PT_FLAG_NO_LDS_SCENE, PT_FLAG_TIME_KERNELS, PT_FLAG_NO_COVERAGE_MASK = 1, 2, 4, 8
 PT_FLAG_GPU_BVH, PT_FLAG_HOST_BVH, PT_FLAG_NO_GRAPH, PT_FLAG_NO_FUSE, PT_FLAG_QUEUED_VIEW_RAYS, PT_FLAG_NO_TREELETS, PT_FLAG_STATIC_RUNS = 16, 32, 64, 128, 256, 1024, 512
 PT_FLAG_NO_PIXEL_SUMS = 2048
+PT_FLAG_NO_HIT_ORDER = 4096
 PT_K_NAMES = ('extend', 'connect', 'occluded', 'shade', 'accumulate', 'other', 'raygen', 'raygen_extend', 'shade_occluded',
               'shade_traced', 'sample_traced', 'pixel_traced')
 

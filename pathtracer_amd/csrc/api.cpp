@@ -120,7 +120,7 @@ struct PtHandle {
   DevScene dsc{};
   DevBuf accOwn; float4* acc = nullptr; uint64_t accBytes = 0;
   // wavefront buffers
-  DevBuf bSlotQ, bHitA, bHitB, bRayO, bRayD, bLacc, bRng, bShO, bShD, bShW, bShX, bCounters, bStats;
+  DevBuf bSlotQ, bHitA, bHitB, bHitOrder, bRayO, bRayD, bLacc, bRng, bShO, bShD, bShW, bShX, bCounters, bStats;
   SceneBox box{};
   // coverage mask of the view rays (scene_host.h: buildCoverageMask); rebuilt when the scene or the camera changes
   DevBuf dMask, dSkyMask; bool maskDirty = true, maskUsable = false;
@@ -416,6 +416,7 @@ void ensureWavefront(PtHandle* h) {
   h->bSlotQ.alloc(lean ? 16 : (uint64_t)capSlots * 16);
   uint64_t capHit = capQueue + (uint64_t)PT_SEGS * PT_HIT_SLACK;
   h->bHitA.alloc(capHit * 16); h->bHitB.alloc(capHit * 16);
+  h->bHitOrder.alloc(lean ? 16 : capHit * 4);
   // indirect rays only; as large as the hit arrays, so that the fused shading can use the two pairs alternately as the
   // hit queues of successive bounce rounds (kernels.h: Wavefront::hitOutA)
   h->bRayO.alloc(NI ? capHit * 16 : 16); h->bRayD.alloc(NI ? capHit * 16 : 16);
@@ -441,6 +442,7 @@ void ensureWavefront(PtHandle* h) {
   w.taskCounters = words + h->metas.size() * PT_QMETA_WORDS;
   w.runPool = (h->cfg.flags & PT_FLAG_STATIC_RUNS) ? nullptr : w.taskCounters + PT_TASK_WORDS;
   w.slotQ = h->bSlotQ.as<float4>(); w.hitA = h->bHitA.as<float4>(); w.hitB = h->bHitB.as<float4>();
+  w.hitOrder = lean ? nullptr : h->bHitOrder.as<uint32_t>();
   w.rayO = h->bRayO.as<float4>(); w.rayD = h->bRayD.as<float4>();
   w.Lacc = h->bLacc.as<float4>(); w.rng = h->bRng.as<uint2>();
   w.shO = h->bShO.as<float4>(); w.shD = h->bShD.as<float4>(); w.shW = h->bShW.as<float4>(); w.shX = h->bShX.as<float4>();
@@ -491,6 +493,8 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
   wf.divCap = makeFastDiv(wf.capSlots); wf.round = 0;
   wf.fuse = fuseBits(h, dc, lc, wf);
   wf.chainMask = wf.fuse && dc.mode == 1 ? 1u : 0u;          // (sceneFusable has made sure that the mask fits)
+  // the hits of a scene in global memory are shaded in the order of their cells (kernels.hip: k_hit_order)
+  if (h->dsc.ldsBytes || (h->cfg.flags & PT_FLAG_NO_HIT_ORDER)) wf.hitOrder = nullptr;
   const uint32_t perStage = 2 + PT_MAX_KINDS;
   const int kinds = (int)((dc.hasLights ? h->dsc.numLightGroups : 0) + (dc.hasSky ? 1 : 0));
   const QMeta* desc = ws.devMetas;
@@ -511,6 +515,7 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
     wf.round = primary ? 0u : s - 2u;
     { Timed t(h, PT_K_EXTEND); launchExtend(lc, h->dsc, dc, pm, h->acc, wf, primary); t.done(); }
     scan((size_t)s * perStage, 1);
+    if (wf.hitOrder) { Timed t(h, PT_K_OTHER); launchHitOrder(lc, h->dsc, wf); t.done(); }
     { Timed t(h, PT_K_SHADE); launchShade(lc, h->dsc, dc, pm, h->acc, wf, primary); t.done(); }
     scan((size_t)s * perStage + 1, 1 + kinds);
     launchShadowKinds(h, lc, dc, wf, primary);

@@ -149,6 +149,7 @@ struct Wavefront {
   float4* rayD;               //                     (dir.xyz, 0)
   float4* hitA;               // hit queue (filled by extend, hits only): (hit position.xyz, triangle id)
   float4* hitB;               //                                          (u, v, lane slot, t)
+  uint32_t* hitOrder;         // per entry of the hit queue, or null: the order in which shade takes a segment's hits (launchHitOrder)
   float4* Lacc;               // radiance records.  [0, capSlots): per path slot, the sample's computeLdirect sum or sampleSky
                               // (xyz); w: bits of (material index + 1) when the view ray hit (above bit 24: which
                               // chains' first rays hit, see chainMask), 0 when it missed.  Then, per vertex of a chain,
@@ -229,6 +230,8 @@ void launchScan(const LaunchCfg& lc, const QMeta* metas, int n, uint32_t* taskCo
 // primary: entries of wf.rayIn index wf.slotQ (view direction + path slot); else wf.rayO / wf.rayD
 void launchExtend(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
                   const Wavefront& wf, bool primary);
+// scenes in global memory: fills wf.hitOrder from the hit queue (after its scan, before the shade that reads it)
+void launchHitOrder(const LaunchCfg& lc, const DevScene& sc, const Wavefront& wf);
 void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
                  const Wavefront& wf, bool primary);
 void launchConnect(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const Wavefront& wf, int kind, float area);

@@ -1255,6 +1255,131 @@ __global__ void PT_TRAVERSAL_BOUNDS k_occluded_refill(DevScene sc, float eps, V3
   if ((threadIdx.x & 63) == 0 && nRays) statAdd(stats, STAT_RAYS_OCCL, (unsigned long long)nRays);
 }
 
+// ------------------------------------------------------------------------------------------------ hit order
+// Scenes traversed from global memory: the hits of a hit-queue segment, ordered by the cell of the hit position before
+// they are shaded.  A segment's hits come in the order of the rays, for view rays the order of the pixel tiles: a wave
+// of 64 consecutive hits lies behind 64 neighbouring pixels -- at 64 different depths where the geometry is finer than
+// a pixel, so the light-sample, sun and sky rays that start there share little of what they fetch.  The cell grid is
+// the 16-bit grid of the quantised nodes (DevScene::qBase / qScale) coarsened to at most 2^PT_ORDER_BITS cells per
+// axis, and further until the cells that the segment's hits lie in number at most PT_ORDER_BUCKETS; hits of one cell
+// keep their order (a counting sort: every wave counts a contiguous piece of the segment per cell, one scan over
+// cells x waves, every wave places its piece in order).  order[s * segCap + r] = index within segment s of the hit
+// that is shaded r-th; what shade emits keeps that order (its appends go by wave ballot), so it carries over to all
+// shadow queues and the ray queue of the stage.  Which hit is shaded when does not change any result: every entry
+// belongs to a radiance record of its own.
+#ifndef PT_ORDER_BITS
+#define PT_ORDER_BITS 6
+#endif
+constexpr uint32_t PT_ORDER_THREADS = 1024, PT_ORDER_WAVES = PT_ORDER_THREADS / 64, PT_ORDER_BUCKETS = 256;
+struct CellFrame { uint32_t sh, mn[3], nx, nxy; };
+__device__ __forceinline__ void gridOf(const DevScene& sc, const float4& p, uint32_t g[3]) {
+  const float v[3] = {p.x, p.y, p.z};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) g[k] = (uint32_t)fminf(fmaxf((v[k] - sc.qBase[k]) / sc.qScale[k], 0.0f), 65535.0f);
+}
+__device__ __forceinline__ uint32_t cellKey(const CellFrame& f, const uint32_t g[3]) {
+  return ((g[0] >> f.sh) - f.mn[0]) + f.nx * ((g[1] >> f.sh) - f.mn[1]) + f.nxy * ((g[2] >> f.sh) - f.mn[2]);
+}
+// Lanes of the wave with the same key as this one: how many come before it (rank) and how many there are (n);
+// leader: the first of them.  Converged code; lanes with valid == false take no part.
+__device__ __forceinline__ void rankByKey(bool valid, uint32_t key, uint32_t& rank, uint32_t& n, bool& leader) {
+  bool pending = valid; rank = 0; n = 0; leader = false;
+  const uint32_t lane = threadIdx.x & 63u;
+  for (;;) {
+    const unsigned long long todo = __ballot(pending);
+    if (!todo) break;
+    const uint32_t first = (uint32_t)__ffsll((long long)todo) - 1u;
+    const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)first);
+    const bool mine = pending && key == k0;
+    const unsigned long long m = __ballot(mine);
+    if (mine) {
+      rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      n = (uint32_t)__popcll(m); leader = lane == first; pending = false;
+    }
+  }
+}
+__global__ void __launch_bounds__(PT_ORDER_THREADS) k_hit_order(DevScene sc, QMeta hitQ, uint32_t segCap,
+                                                                const float4* __restrict__ hitA, uint32_t* __restrict__ order) {
+  __shared__ uint32_t sCount[PT_ORDER_WAVES * PT_ORDER_BUCKETS];     // [wave][cell]: count, then where the wave's next hit of the cell goes
+  __shared__ uint32_t sTotal[PT_ORDER_BUCKETS];
+  __shared__ uint32_t sMin[3], sMax[3];
+  const uint32_t seg = blockIdx.x, n = hitQ.prefix[seg + 1] - hitQ.prefix[seg];
+  if (n == 0) return;
+  const float4* in = hitA + (size_t)seg * segCap;
+  uint32_t* out = order + (size_t)seg * segCap;
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+  for (uint32_t i = tid; i < PT_ORDER_WAVES * PT_ORDER_BUCKETS; i += PT_ORDER_THREADS) sCount[i] = 0;
+  if (tid < 3) { sMin[tid] = 0xFFFFu; sMax[tid] = 0u; }
+  __syncthreads();
+  // the box of the segment's hits on the grid
+  uint32_t mn[3] = {0xFFFFu, 0xFFFFu, 0xFFFFu}, mx[3] = {0u, 0u, 0u};
+  for (uint32_t i = tid; i < n; i += PT_ORDER_THREADS) {
+    uint32_t g[3]; gridOf(sc, in[i], g);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { mn[k] = min(mn[k], g[k]); mx[k] = max(mx[k], g[k]); }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    for (int off = 32; off > 0; off >>= 1) { mn[k] = min(mn[k], (uint32_t)__shfl_xor((int)mn[k], off)); mx[k] = max(mx[k], (uint32_t)__shfl_xor((int)mx[k], off)); }
+    if (lane == 0) { atomicMin(&sMin[k], mn[k]); atomicMax(&sMax[k], mx[k]); }
+  }
+  __syncthreads();
+  CellFrame f; f.sh = 16u - PT_ORDER_BITS;
+  for (;; f.sh++) {
+    uint32_t ext[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { f.mn[k] = sMin[k] >> f.sh; ext[k] = (sMax[k] >> f.sh) - f.mn[k] + 1u; }
+    f.nx = ext[0]; f.nxy = ext[0] * ext[1];
+    if ((uint64_t)f.nxy * ext[2] <= PT_ORDER_BUCKETS) break;        // (one cell at the latest when sh = 16)
+  }
+  // every wave a contiguous piece, in steps of 64
+  const uint32_t piece = ((n + PT_ORDER_WAVES - 1u) / PT_ORDER_WAVES + 63u) & ~63u;
+  const uint32_t lo = min(wave * piece, n), hi = min(lo + piece, n);
+  uint32_t* const mine = sCount + wave * PT_ORDER_BUCKETS;
+  for (uint32_t b = lo; b < hi; b += 64u) {
+    const uint32_t i = b + lane; const bool valid = i < hi;
+    uint32_t key = 0;
+    if (valid) { uint32_t g[3]; gridOf(sc, in[i], g); key = cellKey(f, g); }
+    uint32_t rank, cnt; bool leader;
+    rankByKey(valid, key, rank, cnt, leader);
+    if (leader) mine[key] += cnt;
+  }
+  __syncthreads();
+  // exclusive scan, cell-major and wave-minor
+  if (tid < PT_ORDER_BUCKETS) {
+    uint32_t t = 0;
+    for (uint32_t w = 0; w < PT_ORDER_WAVES; ++w) t += sCount[w * PT_ORDER_BUCKETS + tid];
+    sTotal[tid] = t;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    constexpr uint32_t PER = PT_ORDER_BUCKETS / 64;
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) { v[k] = sTotal[lane * PER + k]; sum += v[k]; }
+    uint32_t x = sum;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, off); if (lane >= (uint32_t)off) x += y; }
+    uint32_t run = x - sum;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) { sTotal[lane * PER + k] = run; run += v[k]; }
+  }
+  __syncthreads();
+  if (tid < PT_ORDER_BUCKETS) {
+    uint32_t run = sTotal[tid];
+    for (uint32_t w = 0; w < PT_ORDER_WAVES; ++w) { const uint32_t t = sCount[w * PT_ORDER_BUCKETS + tid]; sCount[w * PT_ORDER_BUCKETS + tid] = run; run += t; }
+  }
+  __syncthreads();
+  for (uint32_t b = lo; b < hi; b += 64u) {
+    const uint32_t i = b + lane; const bool valid = i < hi;
+    uint32_t key = 0;
+    if (valid) { uint32_t g[3]; gridOf(sc, in[i], g); key = cellKey(f, g); }
+    uint32_t rank, cnt; bool leader;
+    rankByKey(valid, key, rank, cnt, leader);
+    if (valid) out[mine[key] + rank] = i;
+    if (leader) mine[key] += cnt;           // (after the reads of this step: the wave's LDS accesses keep their order)
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ shade
 struct ShadeCtx {
   const DevScene& sc; const DevCfg& cfg; const Wavefront& wf; uint32_t* sCnt; uint32_t T, segCapRay, segCapSh;
@@ -1606,6 +1731,7 @@ __device__ __forceinline__ void shadeBody(const DevScene& sc, const DevCfg& cfg,
     Rng g; g.s0 = 1; g.s1 = 0;
     if (active) {
       uint32_t e = physIndex(hitQ, j, seg, wf.capHit / PT_SEGS);
+      if (!FUSE && wf.hitOrder) e = seg.seg * (wf.capHit / PT_SEGS) + wf.hitOrder[e];       // see k_hit_order
       float4 ha = inA[e], hb = inB[e];
       hitPos = xyz(ha); laneSlot = f2u(hb.z);
       uint32_t tri = f2u(ha.w);
@@ -2311,6 +2437,11 @@ void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, 
   PT_DISPATCH_LC(k_occluded, sc, cfg.eps, cfg.sunRadiance, cfg.skyRadiance, envDirect(cfg, sc, primary) ? 1 : 0, wf.sh[kind],
                  wf.capQueue / PT_SEGS, (const float4*)(wf.shO + e), (const float4*)(wf.shD + e), (const float4*)(wf.shW + e),
                  (const float4*)wf.shX, wf.taskCounters + (1 + kind) * PT_TASK_PARTS, wf.Lacc, wf.stats);
+}
+
+void launchHitOrder(const LaunchCfg& lc, const DevScene& sc, const Wavefront& wf) {
+  hipLaunchKernelGGL(k_hit_order, dim3(PT_SEGS), dim3(PT_ORDER_THREADS), 0, lc.stream, sc, wf.hitQ, wf.capHit / PT_SEGS,
+                     (const float4*)wf.hitA, wf.hitOrder);
 }
 
 void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,

@@ -241,12 +241,16 @@ def test_tile_strips_of_a_scene_in_global_memory_do_not_change_the_image(require
     """A scene traversed from global memory numbers its pixel tiles by vertical strips of 32 tiles (frames wider than
     256 pixels), and its shadow kernels hand lanes the next ray.  Whole frames, windows that are not whole rows, bands
     of a frame whose width is not a multiple of the strip (a narrower last strip) and small batches (several chunks per
-    frame): the same bits as the same scene rendered from LDS, where tiles are numbered row by row."""
+    frame): the same bits as the same scene rendered from LDS, where tiles are numbered row by row.  By default the hits
+    of such a scene are shaded in the order of the grid cells they lie in (view-ray hits: a few cells behind a few tiles;
+    hits of the chains in mode 1: cells all over the scene, which the kernel coarsens until they are at most 256);
+    PT_FLAG_NO_HIT_ORDER keeps the order of the rays: the same bits again."""
     fl = soup(1200, seed=31, size=14.0)
     W, H, spp = 808, 96, 3                                                # 101 tiles per row: three strips of 32 and one of 5
     cam = P.Camera(30.0, H / W).setTransform((250, 180, 160), (0, 0, 0), (0, 0, 1))
     out = []
-    for flags, slots in ((0, 0), (P.PT_FLAG_NO_LDS_SCENE, 0), (P.PT_FLAG_NO_LDS_SCENE, 65536)):
+    G = P.PT_FLAG_NO_LDS_SCENE
+    for flags, slots in ((0, 0), (G, 0), (G, 65536), (G | P.PT_FLAG_NO_HIT_ORDER, 0), (G | P.PT_FLAG_NO_HIT_ORDER, 65536)):
         pt = P.PathTracer(W, H, has_sky=1, mode=mode, seed=12, max_depth=2, flags=flags, batch_slots=slots)
         pt.upload_scene(fl['v'], fl['n'], fl['mat_idx'], fl['materials']); pt.set_camera(cam)
         assert pt.stats().sceneInLds == (0 if flags else 1) and pt.stats().numLightGroups >= 1
