@@ -416,7 +416,7 @@ void ensureWavefront(PtHandle* h) {
   h->bSlotQ.alloc(lean ? 16 : (uint64_t)capSlots * 16);
   uint64_t capHit = capQueue + (uint64_t)PT_SEGS * PT_HIT_SLACK;
   h->bHitA.alloc(capHit * 16); h->bHitB.alloc(capHit * 16);
-  h->bHitOrder.alloc(lean ? 16 : capHit * 4);
+  h->bHitOrder.alloc(lean ? 16 : capHit * 16);             // the order and three words per entry for the sort that makes it
   // indirect rays only; as large as the hit arrays, so that the fused shading can use the two pairs alternately as the
   // hit queues of successive bounce rounds (kernels.h: Wavefront::hitOutA)
   h->bRayO.alloc(NI ? capHit * 16 : 16); h->bRayD.alloc(NI ? capHit * 16 : 16);
@@ -495,6 +495,12 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
   wf.chainMask = wf.fuse && dc.mode == 1 ? 1u : 0u;          // (sceneFusable has made sure that the mask fits)
   // the hits of a scene in global memory are shaded in the order of their cells (kernels.hip: k_hit_order)
   if (h->dsc.ldsBytes || (h->cfg.flags & PT_FLAG_NO_HIT_ORDER)) wf.hitOrder = nullptr;
+  wf.regionPix = 0; wf.divRegion = makeFastDiv(1);
+  if (wf.hitOrder && !lc.countVisits) {
+    // the hits of a segment's pixels at all k samples must fit the segment
+    const uint32_t R = (pm.npix + PT_SEGS - 1) / PT_SEGS;
+    if ((uint64_t)R * pm.k <= wf.capHit / PT_SEGS) { wf.regionPix = R; wf.divRegion = makeFastDiv(R); }
+  }
   const uint32_t perStage = 2 + PT_MAX_KINDS;
   const int kinds = (int)((dc.hasLights ? h->dsc.numLightGroups : 0) + (dc.hasSky ? 1 : 0));
   const QMeta* desc = ws.devMetas;
@@ -593,6 +599,7 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
     bind(1);
     { Timed t(h, PT_K_EXTEND); launchExtend(lc, h->dsc, dc, pm, h->acc, wf, true); t.done(); }
     scan((size_t)perStage, 1);
+    if (wf.hitOrder) { Timed t(h, PT_K_OTHER); launchHitOrder(lc, h->dsc, wf); t.done(); }
     { Timed t(h, PT_K_SHADE_OCCLUDED); launchShadeOccluded(lc, h->dsc, dc, pm, h->acc, wf); t.done(); }
   } else {
     stage(1, true);

@@ -149,7 +149,10 @@ struct Wavefront {
   float4* rayD;               //                     (dir.xyz, 0)
   float4* hitA;               // hit queue (filled by extend, hits only): (hit position.xyz, triangle id)
   float4* hitB;               //                                          (u, v, lane slot, t)
-  uint32_t* hitOrder;         // per entry of the hit queue, or null: the order in which shade takes a segment's hits (launchHitOrder)
+  uint32_t* hitOrder;         // 4 words per entry of the hit queue, or null: [0, capHit) the order in which shade takes a
+                              // segment's hits, the rest is what the sort that makes it works in (launchHitOrder)
+  uint32_t regionPix;         // != 0: the hits of the view rays of local pixels [s * regionPix, (s + 1) * regionPix) go to segment s
+  FastDiv divRegion;          //       of the hit queue, whatever their sample (k_extend_refill); 0: segments by the order of the rays
   float4* Lacc;               // radiance records.  [0, capSlots): per path slot, the sample's computeLdirect sum or sampleSky
                               // (xyz); w: bits of (material index + 1) when the view ray hit (above bit 24: which
                               // chains' first rays hit, see chainMask), 0 when it missed.  Then, per vertex of a chain,

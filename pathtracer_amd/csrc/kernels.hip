@@ -788,6 +788,9 @@ struct WaveSupply {
 // LDS have it, a region is a sample of the whole launch, and the rays in flight in the next stage come from all over
 // the frame.)  A segment takes at most P hits, fewer than it holds; lanes of a wave that append to the same segment
 // share one atomic add on its count (a wave's rays come from one or two chunks, so from one or two segments).
+// View rays whose hits are put in order before they are shaded (Wavefront::regionPix != 0, k_hit_order): segment =
+// the pixel's place in the batch / regionPix, so that a segment holds the hits of ALL samples of its 1/PT_SEGS of the
+// batch's pixels -- the denser the hits of a segment lie, the more the rays that start from them have in common.
 // The counts must be zero at launch (launchExtend clears them).
 #ifndef PT_EXTEND_BY_SEGMENT
 #define PT_EXTEND_BY_SEGMENT 1
@@ -829,7 +832,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend_refill(DevScene sc, DevCfg cfg, Pix
 #endif
   if (!PRIMARY && blockIdx.x == 0 && threadIdx.x == 0) statAdd(wf.stats, STAT_RAYS_INDIRECT, (unsigned long long)total);
   SegCursor cur; cur.seg = 0; cur.lo = 1; cur.hi = 0;
-  bool hasRay = false; uint32_t slot = 0, jIn = 0; float carry = 0.0f;
+  bool hasRay = false; uint32_t slot = 0, outSeg = 0; float carry = 0.0f;
   LaneTrav t; idleTrav(t);
   uint32_t stack[64];
   WaveSupply sup;
@@ -847,7 +850,12 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend_refill(DevScene sc, DevCfg cfg, Pix
           float4 ro = wf.rayO[e], rd = wf.rayD[e];
           slot = f2u(ro.w); carry = rd.w; startTrav(sc, t, xyz(ro), xyz(rd));
         }
-        hasRay = true; need = false; jIn = j;
+        hasRay = true; need = false;
+        outSeg = min(j / perTask, PT_SEGS - 1u);
+        if (PRIMARY && wf.regionPix) {          // by the pixel's place in the batch, whatever the sample: see above
+          const uint32_t smp = fdiv(pm.divNpix, slot), lp = slot - smp * pm.npix;
+          outSeg = fdiv(wf.divRegion, lp);
+        }
       }
     }
     if (!__any(hasRay)) break;
@@ -855,7 +863,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend_refill(DevScene sc, DevCfg cfg, Pix
     const bool fin = hasRay && !t.busy();
     const bool isHit = fin && t.found;
 #if PT_EXTEND_BY_SEGMENT
-    const uint32_t seg = min(jIn / perTask, PT_SEGS - 1u);
+    const uint32_t seg = outSeg;
     const uint32_t idx = appendToSegment(isHit, seg, wf.hitQ.count);
     const uint32_t e = seg * segCapOut + idx;
 #else
@@ -1261,54 +1269,118 @@ __global__ void PT_TRAVERSAL_BOUNDS k_occluded_refill(DevScene sc, float eps, V3
 // of 64 consecutive hits lies behind 64 neighbouring pixels -- at 64 different depths where the geometry is finer than
 // a pixel, so the light-sample, sun and sky rays that start there share little of what they fetch.  The cell grid is
 // the 16-bit grid of the quantised nodes (DevScene::qBase / qScale) coarsened to at most 2^PT_ORDER_BITS cells per
-// axis, and further until the cells that the segment's hits lie in number at most PT_ORDER_BUCKETS; hits of one cell
-// keep their order (a counting sort: every wave counts a contiguous piece of the segment per cell, one scan over
-// cells x waves, every wave places its piece in order).  order[s * segCap + r] = index within segment s of the hit
-// that is shaded r-th; what shade emits keeps that order (its appends go by wave ballot), so it carries over to all
-// shadow queues and the ray queue of the stage.  Which hit is shaded when does not change any result: every entry
-// belongs to a radiance record of its own.
+// axis, and further until the box of the segment's hits is at most 65536 cells; the key of a hit is the number of its
+// cell in that box, the axis along which the box has the fewest cells running fastest (behind a patch of pixels the
+// box is long and thin: consecutive keys are consecutive slabs of it).  Hits of one cell keep their order.
+// The sort is a radix sort of the 16-bit keys in two stable counting passes: every wave counts a contiguous piece of
+// the segment per digit value, one scan over values x waves, every wave places its piece in order.
+// order[s * segCap + r] = index within segment s of the hit that is shaded r-th; what shade emits keeps that order
+// (its appends go by wave ballot), so it carries over to all shadow queues and the ray queue of the stage.  Which hit
+// is shaded when does not change any result: every entry belongs to a radiance record of its own.
 #ifndef PT_ORDER_BITS
-#define PT_ORDER_BITS 6
+#define PT_ORDER_BITS 10
 #endif
-constexpr uint32_t PT_ORDER_THREADS = 1024, PT_ORDER_WAVES = PT_ORDER_THREADS / 64, PT_ORDER_BUCKETS = 256;
-struct CellFrame { uint32_t sh, mn[3], nx, nxy; };
+constexpr uint32_t PT_ORDER_THREADS = 1024, PT_ORDER_WAVES = PT_ORDER_THREADS / 64, PT_ORDER_DIGIT = 256;
+struct CellFrame { uint32_t sh, mn[3], m1, m2; int a0, a1, a2; };      // key = c[a0] + m1 * c[a1] + m2 * c[a2]
 __device__ __forceinline__ void gridOf(const DevScene& sc, const float4& p, uint32_t g[3]) {
   const float v[3] = {p.x, p.y, p.z};
 #pragma unroll
   for (int k = 0; k < 3; ++k) g[k] = (uint32_t)fminf(fmaxf((v[k] - sc.qBase[k]) / sc.qScale[k], 0.0f), 65535.0f);
 }
 __device__ __forceinline__ uint32_t cellKey(const CellFrame& f, const uint32_t g[3]) {
-  return ((g[0] >> f.sh) - f.mn[0]) + f.nx * ((g[1] >> f.sh) - f.mn[1]) + f.nxy * ((g[2] >> f.sh) - f.mn[2]);
+  uint32_t c[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) c[k] = (g[k] >> f.sh) - f.mn[k];
+  const uint32_t c0 = f.a0 == 0 ? c[0] : f.a0 == 1 ? c[1] : c[2];
+  const uint32_t c1 = f.a1 == 0 ? c[0] : f.a1 == 1 ? c[1] : c[2];
+  const uint32_t c2 = f.a2 == 0 ? c[0] : f.a2 == 1 ? c[1] : c[2];
+  return c0 + f.m1 * c1 + f.m2 * c2;
 }
-// Lanes of the wave with the same key as this one: how many come before it (rank) and how many there are (n);
-// leader: the first of them.  Converged code; lanes with valid == false take no part.
-__device__ __forceinline__ void rankByKey(bool valid, uint32_t key, uint32_t& rank, uint32_t& n, bool& leader) {
-  bool pending = valid; rank = 0; n = 0; leader = false;
-  const uint32_t lane = threadIdx.x & 63u;
-  for (;;) {
-    const unsigned long long todo = __ballot(pending);
-    if (!todo) break;
-    const uint32_t first = (uint32_t)__ffsll((long long)todo) - 1u;
-    const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)first);
-    const bool mine = pending && key == k0;
-    const unsigned long long m = __ballot(mine);
-    if (mine) {
-      rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      n = (uint32_t)__popcll(m); leader = lane == first; pending = false;
-    }
+// Lanes of the wave with the same 8-bit digit as this one: how many come before it (rank) and how many there are (n);
+// leader: the first of them.  One ballot per bit of the digit, whatever the number of different digits in the wave.
+// Converged code; lanes with valid == false take no part.
+__device__ __forceinline__ void rankByDigit(bool valid, uint32_t d, uint32_t& rank, uint32_t& n, bool& leader) {
+  unsigned long long peers = __ballot(valid);
+#pragma unroll
+  for (uint32_t bit = 0; bit < 8; ++bit) {
+    const bool one = (d >> bit) & 1u;
+    const unsigned long long b = __ballot(one);
+    peers &= one ? b : ~b;
   }
+  rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+  n = (uint32_t)__popcll(peers); leader = valid && rank == 0;
 }
-__global__ void __launch_bounds__(PT_ORDER_THREADS) k_hit_order(DevScene sc, QMeta hitQ, uint32_t segCap,
-                                                                const float4* __restrict__ hitA, uint32_t* __restrict__ order) {
-  __shared__ uint32_t sCount[PT_ORDER_WAVES * PT_ORDER_BUCKETS];     // [wave][cell]: count, then where the wave's next hit of the cell goes
-  __shared__ uint32_t sTotal[PT_ORDER_BUCKETS];
+// One stable counting pass of a workgroup over n (key, index) pairs by the digit (key >> shift) & 255.  inIdx == null:
+// the index of pair r is r.  outKey == null: only the indices are written.  sCount: PT_ORDER_WAVES * PT_ORDER_DIGIT
+// words, sTotal: PT_ORDER_DIGIT words.  Ends with a barrier.
+__device__ __forceinline__ void countingPass(const uint32_t* __restrict__ inKey, const uint32_t* __restrict__ inIdx, uint32_t shift,
+                                             uint32_t* __restrict__ outKey, uint32_t* __restrict__ outIdx, uint32_t n,
+                                             uint32_t* sCount, uint32_t* sTotal) {
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+  for (uint32_t i = tid; i < PT_ORDER_WAVES * PT_ORDER_DIGIT; i += PT_ORDER_THREADS) sCount[i] = 0;
+  __syncthreads();
+  const uint32_t piece = ((n + PT_ORDER_WAVES - 1u) / PT_ORDER_WAVES + 63u) & ~63u;      // every wave a contiguous piece, in steps of 64
+  const uint32_t lo = min(wave * piece, n), hi = min(lo + piece, n);
+  uint32_t* const mine = sCount + wave * PT_ORDER_DIGIT;
+  for (uint32_t b = lo; b < hi; b += 64u) {
+    const uint32_t r = b + lane; const bool valid = r < hi;
+    const uint32_t d = valid ? (inKey[r] >> shift) & (PT_ORDER_DIGIT - 1u) : 0u;
+    uint32_t rank, cnt; bool leader;
+    rankByDigit(valid, d, rank, cnt, leader);
+    if (leader) mine[d] += cnt;
+  }
+  __syncthreads();
+  // exclusive scan, value-major and wave-minor
+  if (tid < PT_ORDER_DIGIT) {
+    uint32_t t = 0;
+    for (uint32_t w = 0; w < PT_ORDER_WAVES; ++w) t += sCount[w * PT_ORDER_DIGIT + tid];
+    sTotal[tid] = t;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    constexpr uint32_t PER = PT_ORDER_DIGIT / 64;
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) { v[k] = sTotal[lane * PER + k]; sum += v[k]; }
+    uint32_t x = sum;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, off); if (lane >= (uint32_t)off) x += y; }
+    uint32_t run = x - sum;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) { sTotal[lane * PER + k] = run; run += v[k]; }
+  }
+  __syncthreads();
+  if (tid < PT_ORDER_DIGIT) {
+    uint32_t run = sTotal[tid];
+    for (uint32_t w = 0; w < PT_ORDER_WAVES; ++w) { const uint32_t t = sCount[w * PT_ORDER_DIGIT + tid]; sCount[w * PT_ORDER_DIGIT + tid] = run; run += t; }
+  }
+  __syncthreads();
+  for (uint32_t b = lo; b < hi; b += 64u) {
+    const uint32_t r = b + lane; const bool valid = r < hi;
+    const uint32_t key = valid ? inKey[r] : 0u, d = (key >> shift) & (PT_ORDER_DIGIT - 1u);
+    uint32_t rank, cnt; bool leader;
+    rankByDigit(valid, d, rank, cnt, leader);
+    if (valid) {
+      const uint32_t pos = mine[d] + rank;
+      outIdx[pos] = inIdx ? inIdx[r] : r;
+      if (outKey) outKey[pos] = key;
+    }
+    if (leader) mine[d] += cnt;             // (after the reads of this step: a wave's LDS accesses keep their order)
+  }
+  __syncthreads();
+}
+// work: 3 words per entry of the hit queue (keys, keys and indices after the first pass)
+__global__ void __launch_bounds__(PT_ORDER_THREADS) k_hit_order(DevScene sc, QMeta hitQ, uint32_t segCap, uint32_t capHit,
+                                                                const float4* __restrict__ hitA, uint32_t* __restrict__ order,
+                                                                uint32_t* __restrict__ work) {
+  __shared__ uint32_t sCount[PT_ORDER_WAVES * PT_ORDER_DIGIT];
+  __shared__ uint32_t sTotal[PT_ORDER_DIGIT];
   __shared__ uint32_t sMin[3], sMax[3];
   const uint32_t seg = blockIdx.x, n = hitQ.prefix[seg + 1] - hitQ.prefix[seg];
   if (n == 0) return;
-  const float4* in = hitA + (size_t)seg * segCap;
-  uint32_t* out = order + (size_t)seg * segCap;
-  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-  for (uint32_t i = tid; i < PT_ORDER_WAVES * PT_ORDER_BUCKETS; i += PT_ORDER_THREADS) sCount[i] = 0;
+  const size_t base = (size_t)seg * segCap;
+  const float4* in = hitA + base;
+  uint32_t* const key0 = work + base; uint32_t* const key1 = work + capHit + base; uint32_t* const idx1 = work + 2 * (size_t)capHit + base;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
   if (tid < 3) { sMin[tid] = 0xFFFFu; sMax[tid] = 0u; }
   __syncthreads();
   // the box of the segment's hits on the grid
@@ -1325,59 +1397,23 @@ __global__ void __launch_bounds__(PT_ORDER_THREADS) k_hit_order(DevScene sc, QMe
   }
   __syncthreads();
   CellFrame f; f.sh = 16u - PT_ORDER_BITS;
+  uint32_t ext[3];
   for (;; f.sh++) {
-    uint32_t ext[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { f.mn[k] = sMin[k] >> f.sh; ext[k] = (sMax[k] >> f.sh) - f.mn[k] + 1u; }
-    f.nx = ext[0]; f.nxy = ext[0] * ext[1];
-    if ((uint64_t)f.nxy * ext[2] <= PT_ORDER_BUCKETS) break;        // (one cell at the latest when sh = 16)
+    if ((uint64_t)ext[0] * ext[1] * ext[2] <= 65536u) break;        // (one cell at the latest when sh = 16)
   }
-  // every wave a contiguous piece, in steps of 64
-  const uint32_t piece = ((n + PT_ORDER_WAVES - 1u) / PT_ORDER_WAVES + 63u) & ~63u;
-  const uint32_t lo = min(wave * piece, n), hi = min(lo + piece, n);
-  uint32_t* const mine = sCount + wave * PT_ORDER_BUCKETS;
-  for (uint32_t b = lo; b < hi; b += 64u) {
-    const uint32_t i = b + lane; const bool valid = i < hi;
-    uint32_t key = 0;
-    if (valid) { uint32_t g[3]; gridOf(sc, in[i], g); key = cellKey(f, g); }
-    uint32_t rank, cnt; bool leader;
-    rankByKey(valid, key, rank, cnt, leader);
-    if (leader) mine[key] += cnt;
-  }
+  // axes by the number of cells, fewest first
+  f.a0 = 0; f.a1 = 1; f.a2 = 2;
+  if (ext[f.a1] < ext[f.a0]) { const int t = f.a0; f.a0 = f.a1; f.a1 = t; }
+  if (ext[f.a2] < ext[f.a1]) { const int t = f.a1; f.a1 = f.a2; f.a2 = t; }
+  if (ext[f.a1] < ext[f.a0]) { const int t = f.a0; f.a0 = f.a1; f.a1 = t; }
+  const uint32_t e0 = f.a0 == 0 ? ext[0] : f.a0 == 1 ? ext[1] : ext[2], e1 = f.a1 == 0 ? ext[0] : f.a1 == 1 ? ext[1] : ext[2];
+  f.m1 = e0; f.m2 = e0 * e1;
+  for (uint32_t i = tid; i < n; i += PT_ORDER_THREADS) { uint32_t g[3]; gridOf(sc, in[i], g); key0[i] = cellKey(f, g); }
   __syncthreads();
-  // exclusive scan, cell-major and wave-minor
-  if (tid < PT_ORDER_BUCKETS) {
-    uint32_t t = 0;
-    for (uint32_t w = 0; w < PT_ORDER_WAVES; ++w) t += sCount[w * PT_ORDER_BUCKETS + tid];
-    sTotal[tid] = t;
-  }
-  __syncthreads();
-  if (wave == 0) {
-    constexpr uint32_t PER = PT_ORDER_BUCKETS / 64;
-    uint32_t v[PER], sum = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < PER; ++k) { v[k] = sTotal[lane * PER + k]; sum += v[k]; }
-    uint32_t x = sum;
-    for (int off = 1; off < 64; off <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, off); if (lane >= (uint32_t)off) x += y; }
-    uint32_t run = x - sum;
-#pragma unroll
-    for (uint32_t k = 0; k < PER; ++k) { sTotal[lane * PER + k] = run; run += v[k]; }
-  }
-  __syncthreads();
-  if (tid < PT_ORDER_BUCKETS) {
-    uint32_t run = sTotal[tid];
-    for (uint32_t w = 0; w < PT_ORDER_WAVES; ++w) { const uint32_t t = sCount[w * PT_ORDER_BUCKETS + tid]; sCount[w * PT_ORDER_BUCKETS + tid] = run; run += t; }
-  }
-  __syncthreads();
-  for (uint32_t b = lo; b < hi; b += 64u) {
-    const uint32_t i = b + lane; const bool valid = i < hi;
-    uint32_t key = 0;
-    if (valid) { uint32_t g[3]; gridOf(sc, in[i], g); key = cellKey(f, g); }
-    uint32_t rank, cnt; bool leader;
-    rankByKey(valid, key, rank, cnt, leader);
-    if (valid) out[mine[key] + rank] = i;
-    if (leader) mine[key] += cnt;           // (after the reads of this step: the wave's LDS accesses keep their order)
-  }
+  countingPass(key0, nullptr, 0u, key1, idx1, n, sCount, sTotal);
+  countingPass(key1, idx1, 8u, nullptr, order + base, n, sCount, sTotal);
 }
 
 // ------------------------------------------------------------------------------------------------ shade
@@ -2104,6 +2140,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_shade_occluded(DevScene sc, DevCfg cfg, Pi
     uint32_t j = ck.begin + (threadIdx.x & 63u);
     if (j < ck.end) {
       uint32_t e = physIndexHint(q, j, ck.seg, segCap, cur);
+      if (!LDSS && wf.hitOrder) e = cur.seg * segCap + wf.hitOrder[e];       // see k_hit_order
       float4 ha = wf.hitA[e], hb = wf.hitB[e];
       const V3 hitPos = xyz(ha); const uint32_t laneSlot = f2u(hb.z);
       uint32_t s = fdiv(pm.divNpix, laneSlot), lp = laneSlot - s * pm.npix;
@@ -2440,8 +2477,8 @@ void launchOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, 
 }
 
 void launchHitOrder(const LaunchCfg& lc, const DevScene& sc, const Wavefront& wf) {
-  hipLaunchKernelGGL(k_hit_order, dim3(PT_SEGS), dim3(PT_ORDER_THREADS), 0, lc.stream, sc, wf.hitQ, wf.capHit / PT_SEGS,
-                     (const float4*)wf.hitA, wf.hitOrder);
+  hipLaunchKernelGGL(k_hit_order, dim3(PT_SEGS), dim3(PT_ORDER_THREADS), 0, lc.stream, sc, wf.hitQ, wf.capHit / PT_SEGS, wf.capHit,
+                     (const float4*)wf.hitA, wf.hitOrder, wf.hitOrder + wf.capHit);
 }
 
 void launchShade(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc,
