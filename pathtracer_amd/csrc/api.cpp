@@ -497,9 +497,9 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
   if (h->dsc.ldsBytes || (h->cfg.flags & PT_FLAG_NO_HIT_ORDER)) wf.hitOrder = nullptr;
   wf.regionPix = 0; wf.divRegion = makeFastDiv(1);
   if (wf.hitOrder && !lc.countVisits) {
-    // the hits of a segment's pixels at all k samples must fit the segment
+    // the view rays and the hits of a segment's pixels at all k samples must fit the segment
     const uint32_t R = (pm.npix + PT_SEGS - 1) / PT_SEGS;
-    if ((uint64_t)R * pm.k <= wf.capHit / PT_SEGS) { wf.regionPix = R; wf.divRegion = makeFastDiv(R); }
+    if ((uint64_t)R * pm.k <= wf.capSlots / PT_SEGS) { wf.regionPix = R; wf.divRegion = makeFastDiv(R); }      // (capHit > capSlots)
   }
   const uint32_t perStage = 2 + PT_MAX_KINDS;
   const int kinds = (int)((dc.hasLights ? h->dsc.numLightGroups : 0) + (dc.hasSky ? 1 : 0));

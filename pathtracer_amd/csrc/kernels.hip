@@ -593,6 +593,15 @@ __global__ void __launch_bounds__(PT_RAYGEN_THREADS) k_raygen(SceneBox box, View
   if (threadIdx.x == 0) sCnt = 0;
   __syncthreads();
   uint32_t T = blockIdx.x, P = dense64(nslots), begin = T * P, end = min(begin + P, nslots);
+  // Wavefront::regionPix != 0: block-task T covers the pixels [T * regionPix, (T + 1) * regionPix) of the batch at all k
+  // samples, sample by sample -- the queue then lists the view rays region by region, and the workgroups of an XCD,
+  // which take a contiguous part of it, trace all samples of a patch of pixels one after the other
+  uint32_t lp0 = 0, Rt = 1;
+  if (wf.regionPix) {
+    lp0 = min(T * wf.regionPix, pm.npix); Rt = min(wf.regionPix, pm.npix - lp0);
+    begin = 0; end = Rt * pm.k;
+    if (Rt == 0) Rt = 1;
+  }
   uint32_t segCap = wf.capSlots / PT_SEGS, culled = 0, nConst = 0;
   // PT_RAYGEN_UNROLL slots per lane and pass, phase by phase: the loads of a phase (mask words, then sample counts)
   // are in flight together, so a pass waits through two memory round trips for four slots, not per slot
@@ -606,6 +615,10 @@ __global__ void __launch_bounds__(PT_RAYGEN_THREADS) k_raygen(SceneBox box, View
     for (int u = 0; u < U; u++) {
       i[u] = base + u * blockDim.x + threadIdx.x;
       valid[u] = i[u] < end;
+      if (wf.regionPix) {
+        const uint32_t r = valid[u] ? i[u] : 0u, smp = r / Rt;
+        i[u] = smp * pm.npix + lp0 + (r - smp * Rt);
+      }
       gp[u] = slotPixel(cfg, pm, valid[u] ? i[u] : begin, s[u]);
       constant[u] = valid[u] && masks.constantSky && maskBit(masks.constantSky, gp[u]);
       enter[u] = false;
