@@ -400,7 +400,7 @@ void ensureWavefront(PtHandle* h) {
     size_t freeB = 0, totalB = 0;
     HIPCHECK(hipMemGetInfo(&freeB, &totalB));
     uint64_t perSlot = 16ull * recLanes + (NI ? 8ull * lanes : 0) + (uint64_t)std::max(1u, NI) * (32 + (NI ? 32 : 0));
-    if (!lean) perSlot += 16 + (uint64_t)std::max(1u, NI) * (48ull * numKinds(h) + 16);
+    if (!lean) perSlot += 16 + (uint64_t)std::max(1u, NI) * (48ull * numKinds(h) + 16 + 16);      // (the last 16: hitOrder)
     uint64_t held = h->wf.capSlots ? (uint64_t)h->wf.capSlots * perSlot : 0;       // what this handle would give back
     while (want > gran && want * perSlot > (freeB + held) / 2) want /= 2;
   }

@@ -49,7 +49,7 @@ def kind_of(name):
     if base == 'k_shade_traced':
         return 'shade' if '<true' in name else 'shade_traced'
     return {'k_extend': 'extend', 'k_extend_refill': 'extend', 'k_connect': 'connect', 'k_connect_refill': 'connect', 'k_occluded': 'occluded', 'k_occluded_refill': 'occluded', 'k_shade': 'shade',
-            'k_accumulate': 'accumulate', 'k_scan': 'other', 'k_raygen': 'raygen', 'k_raygen_extend': 'raygen_extend',
+            'k_accumulate': 'accumulate', 'k_scan': 'other', 'k_hit_order': 'other', 'k_raygen': 'raygen', 'k_raygen_extend': 'raygen_extend',
             'k_shade_occluded': 'shade_occluded', 'k_sample_traced': 'sample_traced', 'k_pixel_traced': 'pixel_traced'}.get(base)
 
 
