@@ -594,13 +594,9 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
   if (wf.fuse) {
     fusedStage(1, true);
     if (dc.mode == 1) fusedStage(2, false);
-  } else if (dc.mode == 0 && envDirect(dc, h->dsc, true) && !lc.countVisits && !(h->cfg.flags & PT_FLAG_NO_FUSE)) {
-    // a vertex spawns nothing but its sun and sky ray: the kernel that traces them shades the hit itself
-    bind(1);
-    { Timed t(h, PT_K_EXTEND); launchExtend(lc, h->dsc, dc, pm, h->acc, wf, true); t.done(); }
-    scan((size_t)perStage, 1);
-    if (wf.hitOrder) { Timed t(h, PT_K_OTHER); launchHitOrder(lc, h->dsc, wf); t.done(); }
-    { Timed t(h, PT_K_SHADE_OCCLUDED); launchShadeOccluded(lc, h->dsc, dc, pm, h->acc, wf); t.done(); }
+  // (A scene in global memory keeps shade and the sun / sky kernel apart even when a vertex spawns nothing else: that
+  // kernel's lanes take the next ray when theirs is decided, which the kernel that shades its hits does not do --
+  // 10 M-triangle soup without its light, 3840x2160, 4 spp: 17.0 + 1.0 ms against 24.7 ms.)
   } else {
     stage(1, true);
     if (dc.mode == 1)      // depth 0..maxDepth can still spawn a ray (the check is depth > maxDepth, rendering.d:380)

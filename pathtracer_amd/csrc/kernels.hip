@@ -2153,7 +2153,6 @@ __global__ void PT_TRAVERSAL_BOUNDS k_shade_occluded(DevScene sc, DevCfg cfg, Pi
     uint32_t j = ck.begin + (threadIdx.x & 63u);
     if (j < ck.end) {
       uint32_t e = physIndexHint(q, j, ck.seg, segCap, cur);
-      if (!LDSS && wf.hitOrder) e = cur.seg * segCap + wf.hitOrder[e];       // see k_hit_order
       float4 ha = wf.hitA[e], hb = wf.hitB[e];
       const V3 hitPos = xyz(ha); const uint32_t laneSlot = f2u(hb.z);
       uint32_t s = fdiv(pm.divNpix, laneSlot), lp = laneSlot - s * pm.npix;
@@ -2525,12 +2524,9 @@ void launchRaygenExtend(const LaunchCfg& lc, const SceneBox& box, const ViewMask
 
 void launchShadeOccluded(const LaunchCfg& lc, const DevScene& sc, const DevCfg& cfg, const PixMap& pm, const float4* acc, const Wavefront& wf) {
   Geo g = traversalGeo(lc, sc, wf.capQueue);
-  if (sc.ldsBytes) {
-    allowLds(lc, (const void*)k_shade_occluded<true>, g.lds);
-    hipLaunchKernelGGL(k_shade_occluded<true>, g.grid, g.block, g.lds, lc.stream, sc, cfg, pm, acc, wf);
-  } else {
-    hipLaunchKernelGGL(k_shade_occluded<false>, g.grid, g.block, 0, lc.stream, sc, cfg, pm, acc, wf);
-  }
+  // scenes in LDS only (renderBatch: a scene in global memory runs k_shade and k_occluded_refill)
+  allowLds(lc, (const void*)k_shade_occluded<true>, g.lds);
+  hipLaunchKernelGGL(k_shade_occluded<true>, g.grid, g.block, g.lds, lc.stream, sc, cfg, pm, acc, wf);
 }
 
 void launchSampleTraced(const LaunchCfg& lc, const SceneBox& box, const ViewMasks& masks, const DevScene& sc, const DevCfg& cfg,
