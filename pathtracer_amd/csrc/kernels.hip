@@ -242,8 +242,30 @@ __device__ __forceinline__ uint32_t popRef(const uint32_t* stack, int& sp) {
   return r;
 }
 
-template <bool LDSS, int OCT, bool UNBOUNDED = false>
-__device__ __forceinline__ uint32_t stepDown(const DevScene& sc, const RayInv& ri, float tmax, uint32_t ref, uint32_t* stack, int& sp) {
+// The traversal stack of a lane: an array in scratch memory (uint32_t*), or -- the kernels for scenes in global memory,
+// whose LDS is idle and whose vector-memory address unit is what bounds them -- the first PT_LDS_STACK levels in LDS
+// (the lane's column of its wave's block: level * 64 + lane, no bank conflicts whatever the lanes' levels) and the
+// rest in scratch memory.
+#ifndef PT_LDS_STACK
+#define PT_LDS_STACK 16
+#endif
+struct LdsStack { uint32_t* lds; uint32_t* rest; };
+__device__ __forceinline__ void stkPush(uint32_t* s, int& sp, uint32_t v) { s[sp++] = v; }
+__device__ __forceinline__ uint32_t stkPop(const uint32_t* s, int& sp) { return popRef(s, sp); }
+__device__ __forceinline__ void stkPush(const LdsStack& s, int& sp, uint32_t v) {
+  if (sp < PT_LDS_STACK) s.lds[sp * 64] = v; else s.rest[sp - PT_LDS_STACK] = v;
+  sp++;
+}
+__device__ __forceinline__ uint32_t stkPop(const LdsStack& s, int& sp) {
+  --sp;
+  uint32_t r;
+  if (sp < PT_LDS_STACK) { r = s.lds[sp * 64]; asm volatile("" : "+v"(r)); }
+  else { r = s.rest[sp - PT_LDS_STACK]; asm volatile("" : "+v"(r)); }
+  return r;
+}
+
+template <bool LDSS, int OCT, bool UNBOUNDED = false, class STK = uint32_t*>
+__device__ __forceinline__ uint32_t stepDown(const DevScene& sc, const RayInv& ri, float tmax, uint32_t ref, STK stack, int& sp) {
   float tn0, tn1;
   bool h0, h1;
   uint32_t r0, r1;
@@ -270,10 +292,10 @@ __device__ __forceinline__ uint32_t stepDown(const DevScene& sc, const RayInv& r
   // the scene in HBM every extra step is a memory round trip and near-first stays ahead (+2 %)
   bool sw = (UNBOUNDED && LDSS) ? (h1 && !h0) : (h1 && (!h0 || tn1 < tn0));
   uint32_t nearRef = sw ? r1 : r0, farRef = sw ? r0 : r1;
-  if (h0 && h1) stack[sp++] = farRef;  // (storing unconditionally above the top was measured: 20 % slower)
+  if (h0 && h1) stkPush(stack, sp, farRef);  // (storing unconditionally above the top was measured: 20 % slower)
   if (h0 || h1) return nearRef;
   if (sp == 0) return PT_NONE;
-  return popRef(stack, sp);
+  return stkPop(stack, sp);
 }
 __device__ __forceinline__ bool isInternal(uint32_t ref) { return (ref >> BVH_COUNT_SHIFT) == 0; }
 __device__ __forceinline__ bool isLeaf(uint32_t ref) { return (ref >> BVH_COUNT_SHIFT) != 0 && ref != PT_NONE; }
@@ -727,6 +749,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend(DevScene sc, DevCfg cfg, PixMap pm,
 #ifndef PT_REFILL_BELOW
 #define PT_REFILL_BELOW 32
 #endif
+constexpr uint32_t PT_REFILL_THREADS = 512;      // workgroup of the kernels for scenes in global memory (traversalGeo)
 
 // A lane's ray and where its traversal of the (quantised, global-memory) tree stands.
 struct LaneTrav {
@@ -751,13 +774,13 @@ __device__ __forceinline__ void startTrav(const DevScene& sc, LaneTrav& t, V3 o,
 }
 // Advances every lane's traversal until fewer than minBusy lanes are still at it (the postponed-leaf loop of
 // traverseOct, resumable; ANY: a lane stops at the first triangle it accepts).  Converged code.
-template <bool ANY>
-__device__ __forceinline__ void advanceTrav(const DevScene& sc, LaneTrav& t, uint32_t* stack, float eps, uint32_t minBusy) {
+template <bool ANY, class STK>
+__device__ __forceinline__ void advanceTrav(const DevScene& sc, LaneTrav& t, STK stack, float eps, uint32_t minBusy) {
   for (;;) {
     if ((uint32_t)__popcll(__ballot(t.busy())) < minBusy) break;
     while (isInternal(t.ref)) {
-      t.ref = stepDown<false, -1, ANY>(sc, t.ri, t.h.t, t.ref, stack, t.sp);
-      if (t.leaf == PT_NONE && isLeaf(t.ref)) { t.leaf = t.ref; t.ref = t.sp ? popRef(stack, t.sp) : PT_NONE; }
+      t.ref = stepDown<false, -1, ANY, STK>(sc, t.ri, t.h.t, t.ref, stack, t.sp);
+      if (t.leaf == PT_NONE && isLeaf(t.ref)) { t.leaf = t.ref; t.ref = t.sp ? stkPop(stack, t.sp) : PT_NONE; }
       if (!__any(t.leaf == PT_NONE && t.ref != PT_NONE)) break;
     }
     while (t.leaf != PT_NONE) {
@@ -766,7 +789,7 @@ __device__ __forceinline__ void advanceTrav(const DevScene& sc, LaneTrav& t, uin
       for (uint32_t i = 0; i < cnt && !stop; i++) stop = testTriangle<ANY, false>(sc, (first + i) * 3, t.o, t.d, eps, t.h, t.found);
       t.leaf = PT_NONE;
       if (ANY && stop) { t.found = true; t.ref = PT_NONE; }
-      else if (isLeaf(t.ref)) { t.leaf = t.ref; t.ref = t.sp ? popRef(stack, t.sp) : PT_NONE; }
+      else if (isLeaf(t.ref)) { t.leaf = t.ref; t.ref = t.sp ? stkPop(stack, t.sp) : PT_NONE; }
     }
   }
 }
@@ -847,7 +870,14 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend_refill(DevScene sc, DevCfg cfg, Pix
   SegCursor cur; cur.seg = 0; cur.lo = 1; cur.hi = 0;
   bool hasRay = false; uint32_t slot = 0, outSeg = 0; float carry = 0.0f;
   LaneTrav t; idleTrav(t);
-  uint32_t stack[64];
+#if PT_LDS_STACK
+  __shared__ uint32_t sStack[(PT_REFILL_THREADS / 64) * PT_LDS_STACK * 64];
+  uint32_t stackRest[64 - PT_LDS_STACK];
+  const LdsStack stack{sStack + (threadIdx.x >> 6) * (PT_LDS_STACK * 64) + (threadIdx.x & 63u), stackRest};
+#else
+  uint32_t stackArr[64];
+  uint32_t* const stack = stackArr;
+#endif
   WaveSupply sup;
   for (;;) {
     bool need = !hasRay;
@@ -1168,7 +1198,14 @@ __global__ void PT_TRAVERSAL_BOUNDS k_connect_refill(DevScene sc, float eps, QMe
   SegCursor cur; cur.seg = 0; cur.lo = 1; cur.hi = 0;
   uint32_t e = 0, slot = 0; bool hasRay = false; float lightDistance = 0.0f;
   LaneTrav t; idleTrav(t);
-  uint32_t stack[64];
+#if PT_LDS_STACK
+  __shared__ uint32_t sStack[(PT_REFILL_THREADS / 64) * PT_LDS_STACK * 64];
+  uint32_t stackRest[64 - PT_LDS_STACK];
+  const LdsStack stack{sStack + (threadIdx.x >> 6) * (PT_LDS_STACK * 64) + (threadIdx.x & 63u), stackRest};
+#else
+  uint32_t stackArr[64];
+  uint32_t* const stack = stackArr;
+#endif
   WaveSupply sup;
   for (;;) {
     if (hasRay && !t.busy()) {
@@ -1227,7 +1264,14 @@ __global__ void PT_TRAVERSAL_BOUNDS k_occluded_refill(DevScene sc, float eps, V3
   uint32_t e = 0, slot = 0; bool haveEntry = false, skyTodo = false, onSky = false, vSun = false, vSky = false, tracing = false;
   float sSun = 0.0f, sSky = 0.0f;
   LaneTrav t; idleTrav(t);
-  uint32_t stack[64];
+#if PT_LDS_STACK
+  __shared__ uint32_t sStack[(PT_REFILL_THREADS / 64) * PT_LDS_STACK * 64];
+  uint32_t stackRest[64 - PT_LDS_STACK];
+  const LdsStack stack{sStack + (threadIdx.x >> 6) * (PT_LDS_STACK * 64) + (threadIdx.x & 63u), stackRest};
+#else
+  uint32_t stackArr[64];
+  uint32_t* const stack = stackArr;
+#endif
   WaveSupply sup;
   for (;;) {
     // lanes whose ray is decided: note the answer, go on with the entry's sky ray or close the entry
@@ -2391,7 +2435,7 @@ Geo traversalGeo(const LaunchCfg& lc, const DevScene& sc, uint64_t maxItems) {
   Geo g; g.lds = sc.ldsBytes;
   uint32_t bs, perCU;
   if (sc.ldsBytes == 0) {
-    bs = 512; perCU = 4;
+    bs = PT_REFILL_THREADS; perCU = 4;
 #ifdef PT_DIAG_ENV
     if (const char* e = getenv("PT_DIAG_PERCU")) perCU = (uint32_t)atoi(e);      // diagnostic builds: occupancy of the global-memory kernels
 #endif
