@@ -747,7 +747,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend(DevScene sc, DevCfg cfg, PixMap pm,
 // entries of its chunk (a new chunk from the pool when that is used up), until the queue is drained.  The traversal is
 // the postponed-leaf loop of traverseOct, resumable.  A ray's result does not depend on its lane or its companions.
 #ifndef PT_REFILL_BELOW
-#define PT_REFILL_BELOW 32
+#define PT_REFILL_BELOW 48
 #endif
 constexpr uint32_t PT_REFILL_THREADS = 512;      // workgroup of the kernels for scenes in global memory (traversalGeo)
 
@@ -1184,7 +1184,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_occluded(DevScene sc, float eps, V3 sunRad
 
 // k_connect for scenes traversed from global memory, with lanes that take the next ray when theirs is decided.
 #ifndef PT_REFILL_CONNECT
-#define PT_REFILL_CONNECT 32
+#define PT_REFILL_CONNECT 48
 #endif
 __global__ void PT_TRAVERSAL_BOUNDS k_connect_refill(DevScene sc, float eps, QMeta q, uint32_t segCap, const float4* __restrict__ shO,
                                                      const float4* __restrict__ shD, const float4* __restrict__ shW,
@@ -1247,7 +1247,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_connect_refill(DevScene sc, float eps, QMe
 // wave's chunk; whenever fewer than PT_REFILL_ANY lanes are traversing, the decided rays are written out and the free
 // lanes supplied.  An entry's L is stored once, when its last ray is decided, in the order sun, sky.
 #ifndef PT_REFILL_ANY
-#define PT_REFILL_ANY 32
+#define PT_REFILL_ANY 48
 #endif
 __global__ void PT_TRAVERSAL_BOUNDS k_occluded_refill(DevScene sc, float eps, V3 sunRadiance, V3 skyRadiance, int direct, QMeta q,
                                                       uint32_t segCap, const float4* __restrict__ shO, const float4* __restrict__ shD,
