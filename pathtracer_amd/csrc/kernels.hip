@@ -310,8 +310,11 @@ __device__ __forceinline__ bool isLeaf(uint32_t ref) { return (ref >> BVH_COUNT_
 // ray do not change the result (the closest hit does not depend on the order in which leaves are visited).
 // Measured: with the scene in LDS the bookkeeping costs more instructions than the better lane utilisation saves
 // (7-10 % slower); with the scene in HBM, where a step is a memory round trip, it is 25-35 % faster.
-template <bool ANY, bool LDSS, bool COUNT, int OCT, bool BOTH = false>
-__device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri, V3 o, V3 d, float eps, Hit& h, uint32_t& cN, uint32_t& cT) {
+// STOP (closest-hit rays, scene in LDS): the traversal ends as soon as a hit at t <= tStop is accepted -- for callers that
+// only ask whether the closest hit lies beyond tStop (advanceTrav has the same for scenes in global memory).
+template <bool ANY, bool LDSS, bool COUNT, int OCT, bool BOTH = false, bool STOP = false>
+__device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri, V3 o, V3 d, float eps, Hit& h, uint32_t& cN, uint32_t& cT,
+                                            float tStop = 0.0f) {
   constexpr bool POSTPONE = !LDSS && !COUNT;
   h.t = PT_FLT_MAX; h.u = 0.0f; h.v = 0.0f; h.tri = 0xFFFFFFFFu; h.front = true;
   bool found = false;
@@ -350,6 +353,7 @@ __device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri
         if (COUNT && !PT_STAMP_ON) cT += 1;
         if (testTriangle<ANY, LDSS, BOTH>(sc, (first + i) * 3, o, d, eps, h, found)) return true;
       }
+      if (STOP && h.t <= tStop) break;
 #ifdef PT_STAMP
       if (COUNT) cT += (uint32_t)(__builtin_amdgcn_s_memtime() - t1);
 #endif
@@ -382,8 +386,9 @@ __device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri
 // octant (view rays of a pixel tile), the variant compiled for that octant runs (measured: 5 % on the view-ray
 // launch; nothing for any-hit queries, which therefore keep one variant).  Otherwise, and for the counting and
 // stand-alone variants, the general one.  Must be called with the lanes that have a ray active and no others.
-template <bool ANY, bool LDSS, bool COUNT, bool BY_OCTANT = !COUNT && !ANY, bool BOTH = false>
-__device__ __forceinline__ bool traverse(const DevScene& sc, V3 o, V3 d, float eps, Hit& h, uint32_t& cN, uint32_t& cT) {
+template <bool ANY, bool LDSS, bool COUNT, bool BY_OCTANT = !COUNT && !ANY, bool BOTH = false, bool STOP = false>
+__device__ __forceinline__ bool traverse(const DevScene& sc, V3 o, V3 d, float eps, Hit& h, uint32_t& cN, uint32_t& cT, float tStop = 0.0f) {
+  static_assert(!STOP || (LDSS && !ANY && !COUNT), "the early end is in the loop for scenes in LDS");
   RayInv ri = makeRayInv(o, d, LDSS ? v3(0, 0, 0) : v3(sc.qBase[0], sc.qBase[1], sc.qBase[2]));
   if constexpr (!LDSS) {     // box planes come as grid coordinates q: plane = qBase + q * qScale
     ri.a0x = fmaf(sc.qBase[0], ri.ix, ri.a0x); ri.a1x = fmaf(sc.qBase[0], ri.ix, ri.a1x); ri.ix = sc.qScale[0] * ri.ix;
@@ -394,18 +399,18 @@ __device__ __forceinline__ bool traverse(const DevScene& sc, V3 o, V3 d, float e
     uint32_t oct = octantOf(ri), o0 = __builtin_amdgcn_readfirstlane(oct);
     if (__all(oct == o0)) {
       switch (o0) {
-        case 0: return traverseOct<ANY, LDSS, COUNT, 0, BOTH>(sc, ri, o, d, eps, h, cN, cT);
-        case 1: return traverseOct<ANY, LDSS, COUNT, 1, BOTH>(sc, ri, o, d, eps, h, cN, cT);
-        case 2: return traverseOct<ANY, LDSS, COUNT, 2, BOTH>(sc, ri, o, d, eps, h, cN, cT);
-        case 3: return traverseOct<ANY, LDSS, COUNT, 3, BOTH>(sc, ri, o, d, eps, h, cN, cT);
-        case 4: return traverseOct<ANY, LDSS, COUNT, 4, BOTH>(sc, ri, o, d, eps, h, cN, cT);
-        case 5: return traverseOct<ANY, LDSS, COUNT, 5, BOTH>(sc, ri, o, d, eps, h, cN, cT);
-        case 6: return traverseOct<ANY, LDSS, COUNT, 6, BOTH>(sc, ri, o, d, eps, h, cN, cT);
-        default: return traverseOct<ANY, LDSS, COUNT, 7, BOTH>(sc, ri, o, d, eps, h, cN, cT);
+        case 0: return traverseOct<ANY, LDSS, COUNT, 0, BOTH, STOP>(sc, ri, o, d, eps, h, cN, cT, tStop);
+        case 1: return traverseOct<ANY, LDSS, COUNT, 1, BOTH, STOP>(sc, ri, o, d, eps, h, cN, cT, tStop);
+        case 2: return traverseOct<ANY, LDSS, COUNT, 2, BOTH, STOP>(sc, ri, o, d, eps, h, cN, cT, tStop);
+        case 3: return traverseOct<ANY, LDSS, COUNT, 3, BOTH, STOP>(sc, ri, o, d, eps, h, cN, cT, tStop);
+        case 4: return traverseOct<ANY, LDSS, COUNT, 4, BOTH, STOP>(sc, ri, o, d, eps, h, cN, cT, tStop);
+        case 5: return traverseOct<ANY, LDSS, COUNT, 5, BOTH, STOP>(sc, ri, o, d, eps, h, cN, cT, tStop);
+        case 6: return traverseOct<ANY, LDSS, COUNT, 6, BOTH, STOP>(sc, ri, o, d, eps, h, cN, cT, tStop);
+        default: return traverseOct<ANY, LDSS, COUNT, 7, BOTH, STOP>(sc, ri, o, d, eps, h, cN, cT, tStop);
       }
     }
   }
-  return traverseOct<ANY, LDSS, COUNT, -1, BOTH>(sc, ri, o, d, eps, h, cN, cT);
+  return traverseOct<ANY, LDSS, COUNT, -1, BOTH, STOP>(sc, ri, o, d, eps, h, cN, cT, tStop);
 }
 
 template <bool COUNT> __device__ __forceinline__ void flushCounts(unsigned long long* stats, int nodeSlot, uint32_t cN, uint32_t cT) {
@@ -774,8 +779,11 @@ __device__ __forceinline__ void startTrav(const DevScene& sc, LaneTrav& t, V3 o,
 }
 // Advances every lane's traversal until fewer than minBusy lanes are still at it (the postponed-leaf loop of
 // traverseOct, resumable; ANY: a lane stops at the first triangle it accepts).  Converged code.
+// tStop (closest-hit rays): a lane whose ray has an accepted hit at t <= tStop is done -- the caller only asks whether
+// the closest hit lies beyond tStop (a light sample: anything nearer than the light point hides it, whichever of the
+// occluders is the nearest).
 template <bool ANY, class STK>
-__device__ __forceinline__ void advanceTrav(const DevScene& sc, LaneTrav& t, STK stack, float eps, uint32_t minBusy) {
+__device__ __forceinline__ void advanceTrav(const DevScene& sc, LaneTrav& t, STK stack, float eps, uint32_t minBusy, float tStop = -PT_FLT_MAX) {
   for (;;) {
     if ((uint32_t)__popcll(__ballot(t.busy())) < minBusy) break;
     while (isInternal(t.ref)) {
@@ -789,6 +797,7 @@ __device__ __forceinline__ void advanceTrav(const DevScene& sc, LaneTrav& t, STK
       for (uint32_t i = 0; i < cnt && !stop; i++) stop = testTriangle<ANY, false>(sc, (first + i) * 3, t.o, t.d, eps, t.h, t.found);
       t.leaf = PT_NONE;
       if (ANY && stop) { t.found = true; t.ref = PT_NONE; }
+      else if (!ANY && t.h.t <= tStop) t.ref = PT_NONE;
       else if (isLeaf(t.ref)) { t.leaf = t.ref; t.ref = t.sp ? stkPop(stack, t.sp) : PT_NONE; }
     }
   }
@@ -1238,7 +1247,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_connect_refill(DevScene sc, float eps, QMe
       }
     }
     if (!__any(hasRay)) break;
-    advanceTrav<false>(sc, t, stack, eps, sup.open ? (uint32_t)PT_REFILL_CONNECT : 1u);
+    advanceTrav<false>(sc, t, stack, eps, sup.open ? (uint32_t)PT_REFILL_CONNECT : 1u, lightDistance - eps);
   }
 }
 
@@ -1643,7 +1652,7 @@ __device__ __forceinline__ V3 directLightTraced(ShadeCtx& cx, const ShadeTables<
         if (sampleLight(tb, g, li, x, normalX, eps, phi, lightDistance, ndot)) {
           cx.nLight++;
           // Scene.trace + `if(distanceY > lightDistance - FloatEpsilon)`, rendering.d:414-425
-          if (traverse<false, true, false, PT_FUSE_OCTANTS>(sc, x + normalX * eps, phi, eps, h, cN, cT) && h.t > lightDistance - eps) {
+          if (traverse<false, true, false, PT_FUSE_OCTANTS, false, true>(sc, x + normalX * eps, phi, eps, h, cN, cT, lightDistance - eps) && h.t > lightDistance - eps) {
             float4 q0 = tb.nrm(3 * h.tri), q1 = tb.nrm(3 * h.tri + 1), q2 = tb.nrm(3 * h.tri + 2);
             V3 normalY = interpNormal(xyz(q0), xyz(q1), xyz(q2), h.u, h.v);
             float4 m = tb.mat(f2u(q0.w));
