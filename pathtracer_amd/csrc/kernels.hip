@@ -263,6 +263,22 @@ __device__ __forceinline__ uint32_t stkPop(const LdsStack& s, int& sp) {
   else { r = s.rest[sp - PT_LDS_STACK]; asm volatile("" : "+v"(r)); }
   return r;
 }
+// The LDS part of the stacks of a workgroup of a kernel for scenes in global memory: a block per wave.  Only kernels that
+// traverse such a scene refer to it (and so have it); they are launched with PT_GLOBAL_THREADS threads (traversalGeo).
+constexpr uint32_t PT_GLOBAL_THREADS = 512;
+constexpr uint32_t PT_STACK_REST = PT_LDS_STACK ? 64 - PT_LDS_STACK : 64;      // levels kept in scratch memory
+#if PT_LDS_STACK
+__shared__ uint32_t sWaveStacks[(PT_GLOBAL_THREADS / 64) * PT_LDS_STACK * 64];
+__device__ __forceinline__ LdsStack globalSceneStack(uint32_t* rest) {
+  return LdsStack{sWaveStacks + (threadIdx.x >> 6) * (PT_LDS_STACK * 64) + (threadIdx.x & 63u), rest};
+}
+#else
+__device__ __forceinline__ uint32_t* globalSceneStack(uint32_t* rest) { return rest; }
+#endif
+// The stack of a traversal: scratch memory for a scene in LDS (mem: 64 words), else globalSceneStack (mem: PT_STACK_REST words).
+template <bool LDSS> __device__ __forceinline__ auto traversalStack(uint32_t* mem) {
+  if constexpr (LDSS) return mem; else return globalSceneStack(mem);
+}
 
 template <bool LDSS, int OCT, bool UNBOUNDED = false, class STK = uint32_t*>
 __device__ __forceinline__ uint32_t stepDown(const DevScene& sc, const RayInv& ri, float tmax, uint32_t ref, STK stack, int& sp) {
@@ -318,7 +334,8 @@ __device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri
   constexpr bool POSTPONE = !LDSS && !COUNT;
   h.t = PT_FLT_MAX; h.u = 0.0f; h.v = 0.0f; h.tri = 0xFFFFFFFFu; h.front = true;
   bool found = false;
-  uint32_t stack[64];
+  uint32_t stackMem[LDSS ? 64 : PT_STACK_REST];
+  const auto stack = traversalStack<LDSS>(stackMem);
   int sp = 0;
   uint32_t ref = sc.rootRef;
   if constexpr (!POSTPONE) {
@@ -358,7 +375,7 @@ __device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri
       if (COUNT) cT += (uint32_t)(__builtin_amdgcn_s_memtime() - t1);
 #endif
       if (sp == 0) break;
-      ref = popRef(stack, sp);
+      ref = stkPop(stack, sp);
     }
   } else {
     uint32_t leaf = PT_NONE;
@@ -366,7 +383,7 @@ __device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri
     for (;;) {
       while (isInternal(ref)) {
         ref = stepDown<LDSS, OCT, ANY>(sc, ri, h.t, ref, stack, sp);
-        if (leaf == PT_NONE && isLeaf(ref)) { leaf = ref; ref = sp ? popRef(stack, sp) : PT_NONE; }
+        if (leaf == PT_NONE && isLeaf(ref)) { leaf = ref; ref = sp ? stkPop(stack, sp) : PT_NONE; }
         if (!__any(leaf == PT_NONE && ref != PT_NONE)) break;
       }
       while (leaf != PT_NONE) {
@@ -374,7 +391,7 @@ __device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri
         for (uint32_t i = 0; i < cnt; i++)
           if (testTriangle<ANY, LDSS, BOTH>(sc, (first + i) * 3, o, d, eps, h, found)) return true;
         leaf = PT_NONE;
-        if (isLeaf(ref)) { leaf = ref; ref = sp ? popRef(stack, sp) : PT_NONE; }
+        if (isLeaf(ref)) { leaf = ref; ref = sp ? stkPop(stack, sp) : PT_NONE; }
       }
       if (ref == PT_NONE) break;
     }
@@ -754,7 +771,6 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend(DevScene sc, DevCfg cfg, PixMap pm,
 #ifndef PT_REFILL_BELOW
 #define PT_REFILL_BELOW 48
 #endif
-constexpr uint32_t PT_REFILL_THREADS = 512;      // workgroup of the kernels for scenes in global memory (traversalGeo)
 
 // A lane's ray and where its traversal of the (quantised, global-memory) tree stands.
 struct LaneTrav {
@@ -879,14 +895,8 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend_refill(DevScene sc, DevCfg cfg, Pix
   SegCursor cur; cur.seg = 0; cur.lo = 1; cur.hi = 0;
   bool hasRay = false; uint32_t slot = 0, outSeg = 0; float carry = 0.0f;
   LaneTrav t; idleTrav(t);
-#if PT_LDS_STACK
-  __shared__ uint32_t sStack[(PT_REFILL_THREADS / 64) * PT_LDS_STACK * 64];
-  uint32_t stackRest[64 - PT_LDS_STACK];
-  const LdsStack stack{sStack + (threadIdx.x >> 6) * (PT_LDS_STACK * 64) + (threadIdx.x & 63u), stackRest};
-#else
-  uint32_t stackArr[64];
-  uint32_t* const stack = stackArr;
-#endif
+  uint32_t stackRest[PT_STACK_REST];
+  const auto stack = globalSceneStack(stackRest);
   WaveSupply sup;
   for (;;) {
     bool need = !hasRay;
@@ -1207,14 +1217,8 @@ __global__ void PT_TRAVERSAL_BOUNDS k_connect_refill(DevScene sc, float eps, QMe
   SegCursor cur; cur.seg = 0; cur.lo = 1; cur.hi = 0;
   uint32_t e = 0, slot = 0; bool hasRay = false; float lightDistance = 0.0f;
   LaneTrav t; idleTrav(t);
-#if PT_LDS_STACK
-  __shared__ uint32_t sStack[(PT_REFILL_THREADS / 64) * PT_LDS_STACK * 64];
-  uint32_t stackRest[64 - PT_LDS_STACK];
-  const LdsStack stack{sStack + (threadIdx.x >> 6) * (PT_LDS_STACK * 64) + (threadIdx.x & 63u), stackRest};
-#else
-  uint32_t stackArr[64];
-  uint32_t* const stack = stackArr;
-#endif
+  uint32_t stackRest[PT_STACK_REST];
+  const auto stack = globalSceneStack(stackRest);
   WaveSupply sup;
   for (;;) {
     if (hasRay && !t.busy()) {
@@ -1273,14 +1277,8 @@ __global__ void PT_TRAVERSAL_BOUNDS k_occluded_refill(DevScene sc, float eps, V3
   uint32_t e = 0, slot = 0; bool haveEntry = false, skyTodo = false, onSky = false, vSun = false, vSky = false, tracing = false;
   float sSun = 0.0f, sSky = 0.0f;
   LaneTrav t; idleTrav(t);
-#if PT_LDS_STACK
-  __shared__ uint32_t sStack[(PT_REFILL_THREADS / 64) * PT_LDS_STACK * 64];
-  uint32_t stackRest[64 - PT_LDS_STACK];
-  const LdsStack stack{sStack + (threadIdx.x >> 6) * (PT_LDS_STACK * 64) + (threadIdx.x & 63u), stackRest};
-#else
-  uint32_t stackArr[64];
-  uint32_t* const stack = stackArr;
-#endif
+  uint32_t stackRest[PT_STACK_REST];
+  const auto stack = globalSceneStack(stackRest);
   WaveSupply sup;
   for (;;) {
     // lanes whose ray is decided: note the answer, go on with the entry's sky ray or close the entry
@@ -2444,7 +2442,7 @@ Geo traversalGeo(const LaunchCfg& lc, const DevScene& sc, uint64_t maxItems) {
   Geo g; g.lds = sc.ldsBytes;
   uint32_t bs, perCU;
   if (sc.ldsBytes == 0) {
-    bs = PT_REFILL_THREADS; perCU = 4;
+    bs = PT_GLOBAL_THREADS; perCU = 4;
 #ifdef PT_DIAG_ENV
     if (const char* e = getenv("PT_DIAG_PERCU")) perCU = (uint32_t)atoi(e);      // diagnostic builds: occupancy of the global-memory kernels
 #endif
