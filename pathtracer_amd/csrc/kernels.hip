@@ -771,6 +771,18 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend(DevScene sc, DevCfg cfg, PixMap pm,
 #ifndef PT_REFILL_BELOW
 #define PT_REFILL_BELOW 48
 #endif
+// (advanceTrav: LEAF_WAIT) measured on the 10 M-triangle soup, 1 / 4 / 8 / 16 / 24 / 32 / 44 lanes: view rays 18.9 / 16.9 /
+// 16.1 / 15.6 / 15.8 / 16.7 / 19.6 ms, sun and sky rays 11.2 / 10.5 / 10.4 / 10.5 / 10.7 / 10.9 / 12.3, light samples
+// 10.1 / 10.1 / 10.3 / 10.2 / 10.4 / 10.3 / 10.4
+#ifndef PT_LEAF_WAIT_EXTEND
+#define PT_LEAF_WAIT_EXTEND 16
+#endif
+#ifndef PT_LEAF_WAIT_CONNECT
+#define PT_LEAF_WAIT_CONNECT 1
+#endif
+#ifndef PT_LEAF_WAIT_ANY
+#define PT_LEAF_WAIT_ANY 12
+#endif
 
 // A lane's ray and where its traversal of the (quantised, global-memory) tree stands.
 struct LaneTrav {
@@ -798,14 +810,16 @@ __device__ __forceinline__ void startTrav(const DevScene& sc, LaneTrav& t, V3 o,
 // tStop (closest-hit rays): a lane whose ray has an accepted hit at t <= tStop is done -- the caller only asks whether
 // the closest hit lies beyond tStop (a light sample: anything nearer than the light point hides it, whichever of the
 // occluders is the nearest).
-template <bool ANY, class STK>
+// LEAF_WAIT: the descent goes on while at least that many lanes are still looking for their first leaf (1: until every
+// lane has one); the lanes that are left over sit out the leaf tests and descend on afterwards.
+template <bool ANY, uint32_t LEAF_WAIT, class STK>
 __device__ __forceinline__ void advanceTrav(const DevScene& sc, LaneTrav& t, STK stack, float eps, uint32_t minBusy, float tStop = -PT_FLT_MAX) {
   for (;;) {
     if ((uint32_t)__popcll(__ballot(t.busy())) < minBusy) break;
     while (isInternal(t.ref)) {
       t.ref = stepDown<false, -1, ANY, STK>(sc, t.ri, t.h.t, t.ref, stack, t.sp);
       if (t.leaf == PT_NONE && isLeaf(t.ref)) { t.leaf = t.ref; t.ref = t.sp ? stkPop(stack, t.sp) : PT_NONE; }
-      if (!__any(t.leaf == PT_NONE && t.ref != PT_NONE)) break;
+      if ((uint32_t)__popcll(__ballot(t.leaf == PT_NONE && t.ref != PT_NONE)) < LEAF_WAIT) break;
     }
     while (t.leaf != PT_NONE) {
       uint32_t cnt = t.leaf >> BVH_COUNT_SHIFT, first = t.leaf & BVH_INDEX_MASK;
@@ -921,7 +935,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_extend_refill(DevScene sc, DevCfg cfg, Pix
       }
     }
     if (!__any(hasRay)) break;
-    advanceTrav<false>(sc, t, stack, cfg.eps, sup.open ? (uint32_t)PT_REFILL_BELOW : 1u);
+    advanceTrav<false, PT_LEAF_WAIT_EXTEND>(sc, t, stack, cfg.eps, sup.open ? (uint32_t)PT_REFILL_BELOW : 1u);
     const bool fin = hasRay && !t.busy();
     const bool isHit = fin && t.found;
 #if PT_EXTEND_BY_SEGMENT
@@ -1251,7 +1265,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_connect_refill(DevScene sc, float eps, QMe
       }
     }
     if (!__any(hasRay)) break;
-    advanceTrav<false>(sc, t, stack, eps, sup.open ? (uint32_t)PT_REFILL_CONNECT : 1u, lightDistance - eps);
+    advanceTrav<false, PT_LEAF_WAIT_CONNECT>(sc, t, stack, eps, sup.open ? (uint32_t)PT_REFILL_CONNECT : 1u, lightDistance - eps);
   }
 }
 
@@ -1321,7 +1335,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_occluded_refill(DevScene sc, float eps, V3
       }
     }
     if (!__any(tracing)) break;
-    advanceTrav<true>(sc, t, stack, eps, sup.open ? (uint32_t)PT_REFILL_ANY : 1u);
+    advanceTrav<true, PT_LEAF_WAIT_ANY>(sc, t, stack, eps, sup.open ? (uint32_t)PT_REFILL_ANY : 1u);
   }
   for (int off = 32; off > 0; off >>= 1) nRays += __shfl_down(nRays, off);
   if ((threadIdx.x & 63) == 0 && nRays) statAdd(stats, STAT_RAYS_OCCL, (unsigned long long)nRays);
