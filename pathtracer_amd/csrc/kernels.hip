@@ -384,7 +384,9 @@ __device__ __forceinline__ bool traverseOct(const DevScene& sc, const RayInv& ri
       while (isInternal(ref)) {
         ref = stepDown<LDSS, OCT, ANY>(sc, ri, h.t, ref, stack, sp);
         if (leaf == PT_NONE && isLeaf(ref)) { leaf = ref; ref = sp ? stkPop(stack, sp) : PT_NONE; }
-        if (!__any(leaf == PT_NONE && ref != PT_NONE)) break;
+        // on to the leaf tests when fewer than a quarter of the wave's lanes that are still traversing look for their
+        // first leaf (waiting for the last of them leaves most lanes idle: advanceTrav, LEAF_WAIT)
+        if ((uint32_t)__popcll(__ballot(leaf == PT_NONE && ref != PT_NONE)) * 4u < (uint32_t)__popcll(__ballot(1))) break;
       }
       while (leaf != PT_NONE) {
         uint32_t cnt = leaf >> BVH_COUNT_SHIFT, first = leaf & BVH_INDEX_MASK;
@@ -1274,7 +1276,7 @@ __global__ void PT_TRAVERSAL_BOUNDS k_connect_refill(DevScene sc, float eps, QMe
 // wave's chunk; whenever fewer than PT_REFILL_ANY lanes are traversing, the decided rays are written out and the free
 // lanes supplied.  An entry's L is stored once, when its last ray is decided, in the order sun, sky.
 #ifndef PT_REFILL_ANY
-#define PT_REFILL_ANY 48
+#define PT_REFILL_ANY 40
 #endif
 __global__ void PT_TRAVERSAL_BOUNDS k_occluded_refill(DevScene sc, float eps, V3 sunRadiance, V3 skyRadiance, int direct, QMeta q,
                                                       uint32_t segCap, const float4* __restrict__ shO, const float4* __restrict__ shD,
