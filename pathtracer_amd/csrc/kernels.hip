@@ -813,7 +813,8 @@ __device__ __forceinline__ void startTrav(const DevScene& sc, LaneTrav& t, V3 o,
 // the closest hit lies beyond tStop (a light sample: anything nearer than the light point hides it, whichever of the
 // occluders is the nearest).
 // LEAF_WAIT: the descent goes on while at least that many lanes are still looking for their first leaf (1: until every
-// lane has one); the lanes that are left over sit out the leaf tests and descend on afterwards.
+// lane has one); the lanes that are left over sit out the leaf tests and descend on afterwards.  Likewise the leaf
+// tests go on while at least that many lanes have another leaf at hand (-3 % on top).
 template <bool ANY, uint32_t LEAF_WAIT, class STK>
 __device__ __forceinline__ void advanceTrav(const DevScene& sc, LaneTrav& t, STK stack, float eps, uint32_t minBusy, float tStop = -PT_FLT_MAX) {
   for (;;) {
@@ -831,6 +832,7 @@ __device__ __forceinline__ void advanceTrav(const DevScene& sc, LaneTrav& t, STK
       if (ANY && stop) { t.found = true; t.ref = PT_NONE; }
       else if (!ANY && t.h.t <= tStop) t.ref = PT_NONE;
       else if (isLeaf(t.ref)) { t.leaf = t.ref; t.ref = t.sp ? stkPop(stack, t.sp) : PT_NONE; }
+      if ((uint32_t)__popcll(__ballot(t.leaf != PT_NONE)) < LEAF_WAIT) break;      // the same the other way round
     }
   }
 }
