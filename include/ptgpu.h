@@ -94,10 +94,12 @@ typedef struct PtConfig {
                                      records up in a second launch, as mode 1 does (default, for windows of at least
                                      786432 pixels or one sample per pixel: a lane renders the samples of one pixel one
                                      after the other and adds them up in registers; same sums, bit for bit)            */
-#define PT_FLAG_NO_HIT_ORDER 4096u  /* scenes traversed from global memory: shade the hits in the order of their rays (default:
-                                     within each 1/1024 of the hit queue, in the order of the grid cells the hit positions
-                                     lie in, so that the shadow rays in flight together start close to each other; same
+#define PT_FLAG_NO_HIT_ORDER 4096u  /* scenes traversed from global memory: shade the hits in the order of their rays (default
+                                     for a scene with at least half as many triangles as the frame has pixels: within
+                                     each 1/1024 of the hit queue, in the order of the grid cells the hit positions lie
+                                     in, so that the shadow rays in flight together start close to each other; same
                                      image, bit for bit)                                                                  */
+#define PT_FLAG_HIT_ORDER 8192u     /* that order for any scene traversed from global memory, however coarse its triangles  */
 
 typedef struct PtMaterial { float emissive; float color[3]; } PtMaterial;        /* rendering.d:33-37 */
 typedef struct PtPixel { float color[3]; float n; float sum[3]; } PtPixel;        /* rendering.d:24-30 */

@@ -11,6 +11,7 @@ PT_FLAG_COUNT_VISITS, PT_FLAG_NO_LDS_SCENE, PT_FLAG_TIME_KERNELS, PT_FLAG_NO_COV
 PT_FLAG_GPU_BVH, PT_FLAG_HOST_BVH, PT_FLAG_NO_GRAPH, PT_FLAG_NO_FUSE, PT_FLAG_QUEUED_VIEW_RAYS, PT_FLAG_NO_TREELETS, PT_FLAG_STATIC_RUNS = 16, 32, 64, 128, 256, 1024, 512
 PT_FLAG_NO_PIXEL_SUMS = 2048
 PT_FLAG_NO_HIT_ORDER = 4096
+PT_FLAG_HIT_ORDER = 8192
 PT_K_NAMES = ('extend', 'connect', 'occluded', 'shade', 'accumulate', 'other', 'raygen', 'raygen_extend', 'shade_occluded',
               'shade_traced', 'sample_traced', 'pixel_traced')
 

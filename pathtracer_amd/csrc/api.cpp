@@ -493,8 +493,13 @@ void renderBatch(PtHandle* h, const DevCfg& dc, const LaunchCfg& lc, PixMap pm, 
   wf.divCap = makeFastDiv(wf.capSlots); wf.round = 0;
   wf.fuse = fuseBits(h, dc, lc, wf);
   wf.chainMask = wf.fuse && dc.mode == 1 ? 1u : 0u;          // (sceneFusable has made sure that the mask fits)
-  // the hits of a scene in global memory are shaded in the order of their cells (kernels.hip: k_hit_order)
-  if (h->dsc.ldsBytes || (h->cfg.flags & PT_FLAG_NO_HIT_ORDER)) wf.hitOrder = nullptr;
+  // The hits of a scene in global memory are shaded in the order of their cells (kernels.hip: k_hit_order) when the
+  // geometry is about as fine as the pixels: then neighbouring pixels see hits at unrelated depths and the order of the
+  // pixels is no order in space.  Under coarser geometry the hits of neighbouring pixels are neighbours already, and
+  // the sort and the gathering of the hits only cost (the teapot forced into global memory, 1080p: 40.0 -> 50.7 ms per
+  // 256 spp; the 10 M-triangle soup at 3840x2160: 65.5 -> 59.7 ms per 4 spp).
+  const bool fine = (uint64_t)h->dsc.numOrigTris * 2 >= (uint64_t)h->cfg.width * h->cfg.height;
+  if (h->dsc.ldsBytes || (h->cfg.flags & PT_FLAG_NO_HIT_ORDER) || !(fine || (h->cfg.flags & PT_FLAG_HIT_ORDER))) wf.hitOrder = nullptr;
   wf.regionPix = 0; wf.divRegion = makeFastDiv(1);
   if (wf.hitOrder && !lc.countVisits) {
     // the view rays and the hits of a segment's pixels at all k samples must fit the segment

@@ -23,6 +23,7 @@ for c in range(cases):
     sky = int(rng.random() < 0.7 or not (fl['materials'][:, 0] > 0).any())
     mode = int(rng.random() < 0.5)
     glob = P.PT_FLAG_NO_LDS_SCENE if rng.random() < 0.25 else 0
+    if glob and c % 2 == 0: glob |= P.PT_FLAG_HIT_ORDER       # (default only for geometry as fine as the pixels)
     W, H = int(rng.choice([64, 96, 120])), int(rng.choice([48, 64]))
     cam = P.Camera(30.0, H / W).setTransform((250, 180, 160), (0, 0, 0), (0, 0, 1))
     out = []

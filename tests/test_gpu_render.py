@@ -249,7 +249,7 @@ def test_tile_strips_of_a_scene_in_global_memory_do_not_change_the_image(require
     W, H, spp = 808, 96, 3                                                # 101 tiles per row: three strips of 32 and one of 5
     cam = P.Camera(30.0, H / W).setTransform((250, 180, 160), (0, 0, 0), (0, 0, 1))
     out = []
-    G = P.PT_FLAG_NO_LDS_SCENE
+    G = P.PT_FLAG_NO_LDS_SCENE | P.PT_FLAG_HIT_ORDER                     # (the order is the default only for finer geometry than this)
     for flags, slots in ((0, 0), (G, 0), (G, 65536), (G | P.PT_FLAG_NO_HIT_ORDER, 0), (G | P.PT_FLAG_NO_HIT_ORDER, 65536)):
         pt = P.PathTracer(W, H, has_sky=1, mode=mode, seed=12, max_depth=2, flags=flags, batch_slots=slots)
         pt.upload_scene(fl['v'], fl['n'], fl['mat_idx'], fl['materials']); pt.set_camera(cam)
