@@ -3,7 +3,7 @@
 #   scripts/kernel_resources.sh [filter-regex] [extra hipcc flags...]
 cd "$(dirname "$0")/../pathtracer_amd/csrc" || exit 1
 filter="${1:-.}"; shift
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include "$@" -c -o /tmp/kres.o kernels.hip \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -I../../include "$@" -c -o /tmp/kres.o kernels.hip \
   -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
 import re, sys, subprocess
 rows = []; cur = None
