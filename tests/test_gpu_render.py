@@ -268,6 +268,26 @@ def test_tile_strips_of_a_scene_in_global_memory_do_not_change_the_image(require
             assert getattr(sa, f) == getattr(sx, f), f
 
 
+def test_hit_order_is_the_default_only_under_fine_geometry(require_gpu):
+    """A scene in global memory with at least half as many triangles as the frame has pixels gets its hits put in the order
+    of their cells without being asked (one more launch per stage than with PT_FLAG_NO_HIT_ORDER); under coarser geometry
+    only PT_FLAG_HIT_ORDER does that.  The image is the same bits every way."""
+    fl = soup(1200, seed=8, size=14.0)
+    k = list(P.PT_K_NAMES).index('other')
+    for W, H, auto in ((48, 40, True), (160, 96, False)):                    # 2400 >= 1920 pixels; 2400 < 15360
+        cam = P.Camera(30.0, H / W).setTransform((250, 180, 160), (0, 0, 0), (0, 0, 1))
+        out = []
+        for extra in (0, P.PT_FLAG_HIT_ORDER, P.PT_FLAG_NO_HIT_ORDER):
+            pt = P.PathTracer(W, H, has_sky=1, mode=0, seed=4, flags=P.PT_FLAG_NO_LDS_SCENE | P.PT_FLAG_TIME_KERNELS | extra)
+            pt.upload_scene(fl['v'], fl['n'], fl['mat_idx'], fl['materials']); pt.set_camera(cam)
+            pt.render_frame(3)
+            out.append((pt.read_pixels()['sum'].view(np.uint32).copy(), pt.stats().kernelLaunches[k]))
+            pt.close()
+        (a, na), (b, nb), (c, nc) = out
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+        assert nb == nc + 1 and na == (nb if auto else nc), (na, nb, nc)
+
+
 def test_pixel_checkpoint_roundtrip_and_resume(require_gpu, tmp_path):
     """main.d:227-234, 333-340: raw Pixel[] dump and restore; resuming continues the same sample sequence."""
     name, W, H = 'cornell-box', 64, 40
